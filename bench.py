@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- acoustic frames/s (fbank -> CMVN -> nnet log-likelihoods) on N MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the whole hot path over one batch of synthetic utterances
+whose PCM is already resident in HBM.  Workload (BASELINE.json configs[2] per GPU,
+configs[3] at N = 8): 256 utterances x 10 s of 16 kHz audio per GPU (255 488
+frames), model S = 440 -> 4 x 1024 ReLU -> 3000 softmax, fp32 MFMA.  Utterances are
+sharded over ranks (u -> rank u mod N), weights are broadcast once from rank 0 over
+RCCL, there is no data-path collective: scaling is weak.
+
+Rank 0 prints ONE JSON line with the contract keys plus "roofline" (the affine-GEMM
+kernel, timed live with HIP events on the stream it runs on) and "cpu_baseline"
+(the oracle port timed on this box's host cores, bounded sample, N = 1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def cpu_baseline(model_name, seconds, num_utts):
+    """Oracle port (oracle/pk_oracle*.c: scalar fbank/CMVN + blocked AVX2 SGEMM of the
+    reference's class), ONE thread, on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    from pocketkaldi_amd import synth
+    layers, prior, L, R = synth.model(model_name)
+    nn = O.Nnet(layers)
+    fb = O.Fbank()
+    g = synth.global_cmvn_stats()
+    waves = [synth.utterance(u, seconds) for u in range(num_utts)]
+    frames = 0
+    t0 = time.perf_counter()
+    for w in waves:
+        feats = O.cmvn(g, fb.compute(w))
+        nn.am_compute(feats, prior, L, R, 0.1)
+        frames += feats.shape[0]
+    dt = time.perf_counter() - t0
+    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d utterances x %.0f s (%d frames), model %s, whole path, %.1f s of CPU"
+                      % (num_utts, seconds, frames, model_name, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
+    ap.add_argument("--seconds", type=float, default=10.0, help="audio per utterance")
+    ap.add_argument("--model", default="S", choices=["S", "W", "tiny"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-utts", type=int, default=16)
+    args = ap.parse_args()
+
+    import torch
+    import pocketkaldi_amd as pk
+    from pocketkaldi_amd import dist as pkdist
+    from pocketkaldi_amd import synth
+
+    rank, local_rank, world = pkdist.env_world()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pk.set_device(local_rank)
+    pkdist.init("nccl")
+
+    # ---- model: every rank builds the same structure; only rank 0 has real values
+    layers, prior, L, R = synth.model(args.model)
+    if rank != 0:
+        layers = [(l[0], np.zeros_like(l[1]), np.zeros_like(l[2])) if l[0] == "linear" else l
+                  for l in layers]
+        prior = np.full_like(prior, 1.0)
+    am = pk.AcousticModel(layers, prior, L, R)
+    if world > 1:
+        ptr, nbytes = am.blob()
+        blob = pkdist.alias_device_bytes(ptr, nbytes, dev)
+        pkdist.broadcast_blob(blob, src=0)          # the one RCCL collective of the path
+        torch.cuda.synchronize()
+
+    # ---- synthetic PCM, resident in HBM before any timed region
+    ids = pkdist.utterance_ids(rank, world, args.batch)
+    waves = [synth.utterance(u, args.seconds) for u in ids]
+    ns = [len(w) for w in waves]
+    pcm = torch.from_numpy(np.concatenate(waves)).to(dev)
+    bs = pk.BatchScorer(am, synth.global_cmvn_stats(), args.batch, int(sum(ns)))
+    bs.set_waves_device(pcm.data_ptr(), ns, keep_alive=pcm)
+    frames_per_step = bs.total_frames()
+
+    # ---- broadcast check: every rank scores utterance 0 with its replica
+    if world > 1:
+        chk = pk.BatchScorer(am, synth.global_cmvn_stats(), 1, 16000)
+        chk.set_waves([synth.utterance(0, 1.0)])
+        chk.score(0.1)
+        s = float(np.sum(chk.fetch(0).log_prob().astype(np.float64)))
+        if not pkdist.all_ranks_agree(s, dev):
+            raise SystemExit("weight broadcast mismatch across ranks")
+        chk.close()
+
+    for _ in range(args.warmup):
+        bs.score(0.1, sync=False)
+    bs.synchronize()
+
+    bs.enable_timing(True)
+    pkdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bs.score(0.1, sync=False)
+    torch.cuda.synchronize()
+    pkdist.barrier()
+    dt = time.perf_counter() - t0
+    # events of the LAST step (each score() resets the recorder)
+    tm = bs.timing()
+    dt = pkdist.max_over_ranks(dt, dev)
+    total_frames = pkdist.sum_over_ranks(frames_per_step, dev)
+
+    if rank == 0:
+        value = total_frames * args.steps / dt
+        gemm_ms, gemm_launches = tm["gemm"]
+        flops_per_step = am.flops_per_frame() * frames_per_step
+        achieved = flops_per_step / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        hidden, nh, pdfs = synth.MODELS[args.model]
+        out = {
+            "metric": "acoustic frames/sec (fbank->nnet log-likelihoods)",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%d utterances x %.0f s 16 kHz per GPU (BASELINE configs[2]; x8 = configs[3]), "
+                                   "440 -> %d x %d ReLU -> %d softmax, fbank+CMVN+nnet, PCM resident in HBM"
+                                   % (args.batch, args.seconds, nh, hidden, pdfs),
+                       "model": args.model, "utterances_per_gpu": args.batch,
+                       "frames_per_gpu_per_step": int(frames_per_step),
+                       "parallelism": "utterance-sharded x%d, weights broadcast once (RCCL)" % world},
+            "roofline": {"bound": "mfma", "kernel": "GemmKernel (fp32 MFMA affine layers, %d launches/step)" % gemm_launches,
+                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "flop_per_frame": am.flops_per_frame(),
+                         "kernel_ms_per_step": gemm_ms, "traffic": None},
+            "stage_ms_per_step": {k: tm[k][0] for k in pk.KINDS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.model, args.seconds, args.cpu_utts)
+        print(json.dumps(out), flush=True)
+    pkdist.barrier()
+    bs.close()
+    pkdist.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,224 @@
+/*
+ * pk_mi355.h -- C ABI of libpk_mi355.so: pocketkaldi's acoustic-scoring hot path
+ * (fbank -> CMVN -> splice -> nnet -> log-likelihoods) on AMD MI355X (gfx950).
+ *
+ * This is the drop-in boundary.  Plain C types only; every entry point cites the
+ * reference interface (path:line under the pocketkaldi tree) it replaces.
+ * INTEGRATION.md shows the reference-side change that binds to it.
+ *
+ * Error model: the reference's boundary has no status channel (decodable.h:20-41
+ * are void/float/bool; misuse is assert()).  Here every pk_mi355_* function that
+ * can fail returns 0 on success and a negative code on failure, and
+ * pk_mi355_last_error() returns a thread-local message.  The four pk_decodable_*
+ * functions keep the reference signatures; a device failure inside
+ * pk_decodable_init() leaves log_prob empty (ncol = 0) and sets the error string.
+ * No C++ exception crosses this ABI.  There is no CPU fallback: without a
+ * usable gfx950 device every compute entry point fails.
+ */
+#ifndef PK_MI355_H_
+#define PK_MI355_H_
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- data-layout contract (field order and meaning as in the reference) ---- */
+
+/* matrix.h:20-24 -- column-major; memory is [ncol][nrow], i.e. for features and
+ * log-likelihoods one frame (column) is contiguous.                              */
+typedef struct pk_matrix_t {
+  int ncol;
+  int nrow;
+  float *data;
+} pk_matrix_t;
+
+/* vector.h:39-42 */
+typedef struct pk_vector_t {
+  int dim;
+  float *data;
+} pk_vector_t;
+
+/* Stands where `AcousticModel *` stands in the reference (am.h:23-52): holds the
+ * nnet weights (in HBM), log-priors, context and the tid->pdf map (host).        */
+typedef struct pk_mi355_am pk_mi355_am_t;
+
+/* decodable.h:15-18 -- same size and field offsets on LP64 (16 + 8 bytes).       */
+typedef struct pk_decodable_t {
+  pk_matrix_t log_prob;
+  pk_mi355_am_t *am;
+} pk_decodable_t;
+
+/* Layer kinds, nnet.h:13-16 / nnet.h:28-33 */
+enum {
+  PK_NNET_LINEAR_LAYER = 0,
+  PK_NNET_RELU_LAYER = 1,
+  PK_NNET_NORMALIZE_LAYER = 2,
+  PK_NNET_SOFTMAX_LAYER = 3
+};
+
+/* Error codes */
+enum {
+  PK_MI355_OK = 0,
+  PK_MI355_E_INVALID = -1,   /* bad argument / shape mismatch            */
+  PK_MI355_E_DEVICE = -2,    /* HIP runtime failure or no gfx950 device  */
+  PK_MI355_E_IO = -3,        /* file missing or corrupted                */
+  PK_MI355_E_STATE = -4      /* call order (e.g. model not finalized)    */
+};
+
+const char *pk_mi355_last_error(void);
+
+/* Select the HIP device used by subsequently created objects (default 0).
+ * One process drives one GPU (one rank per GPU in multi-GPU runs).               */
+int pk_mi355_set_device(int device);
+
+/* ------------------------------------------------------------------------- */
+/* The four functions decoder.cc consumes -- decodable.h:20-41, decodable.cc:8-36 */
+/* ------------------------------------------------------------------------- */
+
+/* decodable.cc:8-17.  feats: CMVN'd features, {ncol = T, nrow = feat_dim}, host,
+ * borrowed.  Allocates self->log_prob {ncol = T, nrow = num_pdfs} on the host with
+ * malloc(), fills it with (log softmax - log prior) * prob_scale.                */
+void pk_decodable_init(pk_decodable_t *self, pk_mi355_am_t *am, float prob_scale,
+                       const pk_matrix_t *feats);
+/* decodable.cc:19-22 */
+void pk_decodable_destroy(pk_decodable_t *self);
+/* decodable.cc:24-31: log_prob[frame][tid2pdf[trans_id]] -- host lookup          */
+float pk_decodable_loglikelihood(pk_decodable_t *self, int frame, int trans_id);
+/* decodable.cc:33-36 (frame = -1 on the decoder's first poll -> false)           */
+bool pk_decodable_islastframe(pk_decodable_t *self, int frame);
+
+/* ------------------------------------------------------------------------- */
+/* Acoustic model -- replaces AcousticModel (am.h:23-52) + Nnet (nnet.h:88-104)   */
+/* ------------------------------------------------------------------------- */
+
+pk_mi355_am_t *pk_mi355_am_create(void);
+void pk_mi355_am_destroy(pk_mi355_am_t *am);
+
+/* LinearLayer(W, b), nnet.cc:11-20.  W is [out_dim][in_dim] row-major, the order
+ * of the model file (convert_am.py:77-83); b is [out_dim].                        */
+int pk_mi355_am_add_linear(pk_mi355_am_t *am, int in_dim, int out_dim, const float *W,
+                           const float *b);
+/* ReLULayer / NormalizeLayer / SoftmaxLayer, nnet.cc:38-75                       */
+int pk_mi355_am_add_layer(pk_mi355_am_t *am, int layer_type);
+
+/* AcousticModel::Read tail, am.cc:41-60: prior holds probabilities (the log is
+ * taken here); tid2pdf is indexed by transition-id.  tid2pdf may be NULL (then
+ * pk_decodable_loglikelihood treats trans_id as the pdf index).  Uploads the
+ * packed weight blob to HBM.                                                     */
+int pk_mi355_am_finalize(pk_mi355_am_t *am, const float *prior, int num_pdfs,
+                         int left_context, int right_context, const int32_t *tid2pdf,
+                         int num_tids);
+
+/* Nnet::Read (nnet.cc:132-147) + prior / tid2pdf files (am.cc:28-60): the
+ * NNT0/LAY0/MAT0/VEC0 little-endian section files.  tid2pdf_path may be NULL.    */
+int pk_mi355_am_read(pk_mi355_am_t *am, const char *nnet_path, const char *prior_path,
+                     const char *tid2pdf_path, int left_context, int right_context,
+                     int num_pdfs);
+
+int pk_mi355_am_num_pdfs(const pk_mi355_am_t *am);      /* am.h:38 */
+int pk_mi355_am_input_dim(const pk_mi355_am_t *am);     /* spliced width */
+int pk_mi355_am_transition_to_pdf(const pk_mi355_am_t *am, int trans_id); /* am.h:30-32 */
+
+/* The packed device weight blob (weights, biases, log-priors), for the one RCCL
+ * broadcast of multi-GPU runs: every rank builds the same model structure, rank 0
+ * holds the real values, all ranks broadcast [ptr, ptr+bytes) from rank 0.       */
+void *pk_mi355_am_blob_device_ptr(pk_mi355_am_t *am);
+size_t pk_mi355_am_blob_bytes(const pk_mi355_am_t *am);
+
+/* Nnet::Propagate, nnet.cc:149-163: in {ncol = T, nrow = in_dim} host ->
+ * out {ncol = T, nrow = out_dim} host (out->data is (re)allocated with malloc). */
+int pk_mi355_nnet_propagate(pk_mi355_am_t *am, const pk_matrix_t *in, pk_matrix_t *out);
+
+/* ------------------------------------------------------------------------- */
+/* Front-end -- replaces Fbank (fbank.h:47-110) and CMVN (cmvn.h:17-45)           */
+/* ------------------------------------------------------------------------- */
+
+/* Fbank::CalcNumFrames, fbank.cc:35-42 */
+int pk_mi355_num_frames(int num_samples);
+
+/* Fbank::Compute, fbank.cc:267-292: wave (host, 16 kHz, unscaled sample values)
+ * -> out {ncol = T, nrow = 40} host (resized with malloc/realloc).               */
+int pk_mi355_fbank_compute(const pk_vector_t *wave, pk_matrix_t *out);
+
+/* CMVN(global_stats, raw).GetFrame(t) for t = 0..T-1, cmvn.cc:103-125:
+ * global_stats dim 41 (40 sums + count); raw {ncol = T, nrow = 40} host ->
+ * out {ncol = T, nrow = 40} host.                                                */
+int pk_mi355_cmvn_apply(const pk_vector_t *global_stats, const pk_matrix_t *raw,
+                        pk_matrix_t *out);
+
+/* ------------------------------------------------------------------------- */
+/* Batched scorer: many utterances in flight, PCM in -> log-likelihoods out,     */
+/* everything device-resident (the stages of pk_process, pocketkaldi.cc:176-218). */
+/* ------------------------------------------------------------------------- */
+
+typedef struct pk_mi355_batch pk_mi355_batch_t;
+
+/* global_stats41: the cmvn_stats vector pk_load reads (pocketkaldi.cc:96-112).
+ * Capacity: at most max_utts utterances and max_total_samples PCM samples.       */
+pk_mi355_batch_t *pk_mi355_batch_create(pk_mi355_am_t *am, const float *global_stats41,
+                                        int max_utts, int64_t max_total_samples);
+void pk_mi355_batch_destroy(pk_mi355_batch_t *b);
+
+/* Hand over B utterances as host PCM (float sample values as pk_16kpcm_read
+ * produces them, pcm_reader.cc:189-211); copied to HBM.                          */
+int pk_mi355_batch_set_waves(pk_mi355_batch_t *b, const pk_vector_t *waves, int num_utts);
+/* Same, from one concatenated host int16 buffer (the WAV payload itself).        */
+int pk_mi355_batch_set_waves_i16(pk_mi355_batch_t *b, const int16_t *samples,
+                                 const int *num_samples, int num_utts);
+/* Same, PCM already resident in HBM: d_samples is a device pointer to the
+ * concatenated float samples of all utterances.                                  */
+int pk_mi355_batch_set_waves_device(pk_mi355_batch_t *b, const float *d_samples,
+                                    const int *num_samples, int num_utts);
+
+/* Run fbank -> CMVN -> nnet -> log-likelihood tail for the current utterances.
+ * Asynchronous on the batch's stream unless sync != 0.  Results stay in HBM.     */
+int pk_mi355_batch_score(pk_mi355_batch_t *b, float prob_scale, int sync);
+int pk_mi355_batch_synchronize(pk_mi355_batch_t *b);
+
+int pk_mi355_batch_num_utts(const pk_mi355_batch_t *b);
+int pk_mi355_batch_num_frames(const pk_mi355_batch_t *b, int utt);
+int64_t pk_mi355_batch_total_frames(const pk_mi355_batch_t *b);
+
+/* Device pointer to utterance utt's [T][num_pdfs] log-likelihoods.               */
+const float *pk_mi355_batch_loglik_device(const pk_mi355_batch_t *b, int utt);
+/* Copy utterance utt's results into a host decodable (malloc'd log_prob), ready
+ * for Decoder::Decode (decoder.cc:39).                                           */
+int pk_mi355_batch_fetch(pk_mi355_batch_t *b, int utt, pk_decodable_t *out);
+/* Intermediate stages, for parity tests: raw fbank / CMVN'd features of utt,
+ * copied to host as [T][40].                                                     */
+int pk_mi355_batch_fetch_fbank(pk_mi355_batch_t *b, int utt, float *out);
+int pk_mi355_batch_fetch_cmvn(pk_mi355_batch_t *b, int utt, float *out);
+
+/* The HIP stream the batch launches on (hipStream_t as void*), so callers can
+ * bracket it with their own events.                                              */
+void *pk_mi355_batch_stream(pk_mi355_batch_t *b);
+
+/* Per-kernel timing of the LAST score call measured with hipEvents on the batch's
+ * stream (enable before scoring).  Kinds index the arrays below.                 */
+enum {
+  PK_MI355_K_FBANK = 0,
+  PK_MI355_K_CMVN = 1,
+  PK_MI355_K_GEMM = 2,       /* all affine-layer launches */
+  PK_MI355_K_TAIL = 3,       /* log-softmax / prior / scale */
+  PK_MI355_K_OTHER = 4,
+  PK_MI355_K_COUNT = 5
+};
+int pk_mi355_batch_enable_timing(pk_mi355_batch_t *b, int enable);
+/* total milliseconds and launch count per kind for the last score call           */
+int pk_mi355_batch_get_timing(pk_mi355_batch_t *b, float ms[PK_MI355_K_COUNT],
+                              int launches[PK_MI355_K_COUNT]);
+/* algorithmic FLOPs of the affine layers per frame (2 * sum K*N)                 */
+double pk_mi355_am_flops_per_frame(const pk_mi355_am_t *am);
+
+/* Library / device facts */
+int pk_mi355_device_count(void);
+const char *pk_mi355_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* PK_MI355_H_ */

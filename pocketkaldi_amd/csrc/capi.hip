@@ -1,0 +1,1085 @@
+// capi.hip -- the C ABI of libpk_mi355.so (include/pk_mi355.h): model management,
+// the layer executor, the batched scorer and the reference-compatible
+// pk_decodable_* functions.  Host C++ over the HIP runtime; no CPU compute path.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/pk_mi355.h"
+#include "pk_kernels.h"
+#include "pk_tables.h"
+
+using namespace pkmi;
+
+// ------------------------------------------------------------------ errors
+
+namespace {
+
+thread_local char g_err[512] = "";
+int g_device = 0;
+
+int Fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return Fail(PK_MI355_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                 \
+  } while (0)
+
+inline int64_t RoundUp(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+int UseDevice(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return Fail(PK_MI355_E_DEVICE, "no HIP device available (libpk_mi355 has no CPU fallback)");
+  if (device < 0 || device >= n) return Fail(PK_MI355_E_INVALID, "device %d out of range", device);
+  HIP_TRY(hipSetDevice(device));
+  return 0;
+}
+
+// ------------------------------------------------------------------ timing
+
+struct Timer {
+  bool enabled = false;
+  struct Rec { int kind; hipEvent_t a, b; };
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t Get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+  }
+  void Reset() {
+    for (auto &r : recs) { pool.push_back(r.a); pool.push_back(r.b); }
+    recs.clear();
+  }
+  int Begin(int kind, hipStream_t s) {
+    if (!enabled) return -1;
+    Rec r{kind, Get(), Get()};
+    hipEventRecord(r.a, s);
+    recs.push_back(r);
+    return (int)recs.size() - 1;
+  }
+  void End(int id, hipStream_t s) {
+    if (id >= 0) hipEventRecord(recs[id].b, s);
+  }
+  ~Timer() {
+    Reset();
+    for (auto e : pool) hipEventDestroy(e);
+  }
+};
+
+struct Scoped {
+  Timer *t; int id; hipStream_t s;
+  Scoped(Timer *t_, int kind, hipStream_t s_) : t(t_), id(t_ ? t_->Begin(kind, s_) : -1), s(s_) {}
+  ~Scoped() { if (t) t->End(id, s); }
+};
+
+// ------------------------------------------------------------------ section files
+// "VEC0" i32 bytes(=4n+4) i32 n, n x 4 bytes (vector.cc:393-425);
+// "MAT0" i32 8, i32 rows, i32 cols, rows x VEC0 (matrix.cc:288-319);
+// "NNT0" i32 4, i32 layers; "LAY0" i32 4, i32 type [+ MAT0 W, VEC0 b] (nnet.cc:80-147)
+
+struct FileBuf {
+  std::vector<unsigned char> d;
+  size_t pos = 0;
+  std::string path;
+  int Open(const char *p) {
+    path = p;
+    FILE *f = fopen(p, "rb");
+    if (!f) return Fail(PK_MI355_E_IO, "cannot open %s", p);
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    d.resize(n > 0 ? n : 0);
+    size_t got = n > 0 ? fread(d.data(), 1, n, f) : 0;
+    fclose(f);
+    if ((long)got != n) return Fail(PK_MI355_E_IO, "short read on %s", p);
+    return 0;
+  }
+  bool Tag(const char *t) {
+    if (pos + 4 > d.size() || memcmp(&d[pos], t, 4) != 0) return false;
+    pos += 4;
+    return true;
+  }
+  bool I32(int32_t *v) {
+    if (pos + 4 > d.size()) return false;
+    memcpy(v, &d[pos], 4);
+    pos += 4;
+    return true;
+  }
+  template <typename T>
+  int Vec(std::vector<T> *out) {
+    int32_t bytes, n;
+    if (!Tag("VEC0") || !I32(&bytes) || !I32(&n))
+      return Fail(PK_MI355_E_IO, "VEC0 section expected in %s", path.c_str());
+    if (n < 0 || bytes != n * 4 + 4 || pos + (size_t)n * 4 > d.size())
+      return Fail(PK_MI355_E_IO, "corrupted VEC0 section in %s", path.c_str());
+    out->resize(n);
+    if (n) memcpy(out->data(), &d[pos], (size_t)n * 4);
+    pos += (size_t)n * 4;
+    return 0;
+  }
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------ model
+
+struct HostLayer {
+  int type = 0;
+  int in_dim = 0, out_dim = 0;
+  std::vector<float> W;   // [out][in]
+  std::vector<float> b;
+};
+
+struct DevLinear {
+  int K = 0, N = 0, Kpad = 0, Npad = 0;
+  size_t wt_off = 0, b_off = 0;    // float offsets into the blob
+};
+
+struct Workspace;   // forward
+
+struct pk_mi355_am {
+  int device = 0;
+  std::vector<HostLayer> layers;
+  bool finalized = false;
+  int left = 0, right = 0, num_pdfs = 0;
+  int input_dim = 0, output_dim = 0, feat_dim = 0;
+  int max_dim_pad = 0;             // widest activation, rounded to the tile
+  std::vector<int32_t> tid2pdf;
+  std::vector<DevLinear> lin;      // one per linear layer, in order
+  float *d_blob = nullptr;
+  size_t blob_floats = 0;
+  size_t logprior_off = 0;
+  double flops_per_frame = 0;
+  Workspace *ws = nullptr;         // single-utterance workspace of pk_decodable_init
+};
+
+namespace {
+
+// Activation buffers for one chunk of at most `rows_cap` frames.
+struct ExecBufs {
+  float *in = nullptr;    // plain (non-spliced) feature-major input, [Kpad0][rows_cap]
+  float *a = nullptr;     // ping
+  float *b = nullptr;     // pong
+  int64_t rows_cap = 0;
+  int64_t in_floats = 0, act_floats = 0;
+};
+
+int AllocExec(const pk_mi355_am *am, int64_t rows_cap, ExecBufs *e) {
+  e->rows_cap = rows_cap;
+  e->act_floats = (int64_t)am->max_dim_pad * rows_cap;
+  e->in_floats = RoundUp(am->input_dim, kBK) * rows_cap;
+  HIP_TRY(hipMalloc(&e->a, e->act_floats * sizeof(float)));
+  HIP_TRY(hipMalloc(&e->b, e->act_floats * sizeof(float)));
+  HIP_TRY(hipMalloc(&e->in, e->in_floats * sizeof(float)));
+  HIP_TRY(hipMemset(e->a, 0, e->act_floats * sizeof(float)));
+  HIP_TRY(hipMemset(e->b, 0, e->act_floats * sizeof(float)));
+  HIP_TRY(hipMemset(e->in, 0, e->in_floats * sizeof(float)));
+  return 0;
+}
+
+void FreeExec(ExecBufs *e) {
+  hipFree(e->a);
+  hipFree(e->b);
+  hipFree(e->in);
+  *e = ExecBufs();
+}
+
+// Where the result of RunLayers ended up.
+struct ExecResult {
+  const float *data = nullptr;   // frame-major rows
+  int64_t ld = 0;
+  int dim = 0;
+};
+
+// Run the layer stack on `rows` frames (rows_pad = multiple of 128, <= rows_cap).
+// Input: either the spliced view of Yt (splice_dim > 0: q0 points at Yt + first
+// column, ldq = ldy) or the plain feature-major panel in e.in (ld = rows_cap).
+// tail: -1 none (probabilities / raw outputs stay in a buffer, see *res),
+//       otherwise the log-likelihood tail is written to tail_out[row * tail_ld].
+int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t ldq,
+              int splice_dim, int rows, bool want_tail, float scale, float *tail_out,
+              int64_t tail_ld, hipStream_t stream, Timer *timer, ExecResult *res) {
+  const int rows_pad = (int)RoundUp(rows, kTile);
+  if (rows_pad > e.rows_cap) return Fail(PK_MI355_E_INVALID, "chunk larger than workspace");
+  const float *blob = am->d_blob;
+  const int nl = (int)am->layers.size();
+
+  int last_linear = -1;
+  for (int i = 0; i < nl; ++i)
+    if (am->layers[i].type == PK_NNET_LINEAR_LAYER) last_linear = i;
+
+  // current activation: pointer, layout (feature-major panel / frame-major rows), ld, dim
+  const float *cur = splice_dim > 0 ? q0 : e.in;
+  int64_t cur_ld = splice_dim > 0 ? ldq : e.rows_cap;
+  bool cur_rows = false;           // false: feature-major [dim][ld]; true: frame-major [rows][ld]
+  bool cur_splice = splice_dim > 0;
+  int cur_dim = am->input_dim;
+  float *bufs[2] = {e.a, e.b};
+  int next_buf = 0;
+  int li_lin = 0;
+  bool tail_done = false;
+
+  auto to_rows = [&]() {
+    float *dst = bufs[next_buf];
+    const int64_t ld = RoundUp(cur_dim, kTile);
+    Scoped t(timer, PK_MI355_K_OTHER, stream);
+    LaunchTransposeToRows(cur, cur_ld, cur_dim, rows_pad, dst, ld, stream);
+    cur = dst; cur_ld = ld; cur_rows = true; next_buf ^= 1;
+  };
+
+  for (int i = 0; i < nl; ++i) {
+    const HostLayer &L = am->layers[i];
+    switch (L.type) {
+      case PK_NNET_LINEAR_LAYER: {
+        const DevLinear &D = am->lin[li_lin++];
+        if (cur_rows) return Fail(PK_MI355_E_INVALID, "linear layer after a softmax is not supported");
+        const bool fuse_relu = (i + 1 < nl && am->layers[i + 1].type == PK_NNET_RELU_LAYER);
+        const bool rows_out = (i == last_linear) && !cur_splice;
+        float *dst = bufs[next_buf];
+        GemmArgs g;
+        g.K = D.Kpad;
+        g.relu = fuse_relu ? 1 : 0;
+        g.bias = blob + D.b_off;
+        g.out = dst;
+        if (!rows_out) {           // out[feature][frame]
+          g.P = blob + D.wt_off; g.ldp = D.Npad;
+          g.Q = cur; g.ldq = cur_ld;
+          g.splice_dim = cur_splice ? splice_dim : 0;
+          g.bias_on_j = 0;
+          g.ldo = e.rows_cap;
+          g.tiles_i = D.Npad / kTile; g.tiles_j = rows_pad / kTile;
+        } else {                   // out[frame][feature]
+          g.P = cur; g.ldp = cur_ld;
+          g.Q = blob + D.wt_off; g.ldq = D.Npad;
+          g.splice_dim = 0;
+          g.bias_on_j = 1;
+          g.ldo = D.Npad;
+          g.tiles_i = rows_pad / kTile; g.tiles_j = D.Npad / kTile;
+        }
+        {
+          Scoped t(timer, PK_MI355_K_GEMM, stream);
+          LaunchGemm(g, stream);
+        }
+        cur = dst; cur_ld = g.ldo; cur_rows = rows_out; cur_splice = false; cur_dim = D.N;
+        next_buf ^= 1;
+        if (fuse_relu) ++i;
+        break;
+      }
+      case PK_NNET_RELU_LAYER: {
+        if (cur_splice || cur == e.in) {   // never modify inputs in place: copy first
+          float *dst = bufs[next_buf];
+          if (cur_splice) return Fail(PK_MI355_E_INVALID, "network must start with a linear layer when splicing");
+          HIP_TRY(hipMemcpyAsync(dst, cur, sizeof(float) * (size_t)RoundUp(cur_dim, kBK) * e.rows_cap,
+                                 hipMemcpyDeviceToDevice, stream));
+          cur = dst; next_buf ^= 1;
+        }
+        Scoped t(timer, PK_MI355_K_OTHER, stream);
+        const int64_t n = cur_rows ? (int64_t)rows_pad * cur_ld : (int64_t)cur_dim * cur_ld;
+        LaunchRelu(const_cast<float *>(cur), n, stream);
+        break;
+      }
+      case PK_NNET_NORMALIZE_LAYER: {
+        if (cur_splice) return Fail(PK_MI355_E_INVALID, "network must start with a linear layer when splicing");
+        if (cur == e.in) {
+          float *dst = bufs[next_buf];
+          HIP_TRY(hipMemcpyAsync(dst, cur, sizeof(float) * (size_t)RoundUp(cur_dim, kBK) * e.rows_cap,
+                                 hipMemcpyDeviceToDevice, stream));
+          cur = dst; next_buf ^= 1;
+        }
+        Scoped t(timer, PK_MI355_K_OTHER, stream);
+        if (cur_rows) LaunchNormalize(const_cast<float *>(cur), rows_pad, cur_dim, cur_ld, 1, stream);
+        else LaunchNormalize(const_cast<float *>(cur), rows_pad, cur_dim, 1, cur_ld, stream);
+        break;
+      }
+      case PK_NNET_SOFTMAX_LAYER: {
+        if (cur_splice) return Fail(PK_MI355_E_INVALID, "network must start with a linear layer when splicing");
+        if (!cur_rows) to_rows();
+        if (cur_dim > 8192) return Fail(PK_MI355_E_INVALID, "softmax wider than 8192 is not supported");
+        const bool final_layer = (i == nl - 1);
+        Scoped t(timer, PK_MI355_K_TAIL, stream);
+        if (final_layer && want_tail) {
+          LaunchTail(kTailSoftmaxLoglik, cur, cur_ld, rows, cur_dim, blob + am->logprior_off, scale,
+                     tail_out, tail_ld, stream);
+          tail_done = true;
+        } else {
+          float *dst = bufs[next_buf];
+          const int64_t ld = RoundUp(cur_dim, kTile);
+          LaunchTail(kTailSoftmaxProb, cur, cur_ld, rows_pad, cur_dim, nullptr, 1.0f, dst, ld, stream);
+          cur = dst; cur_ld = ld; next_buf ^= 1;
+        }
+        break;
+      }
+      default:
+        return Fail(PK_MI355_E_INVALID, "unknown layer type %d", L.type);
+    }
+  }
+  if (!cur_rows && !tail_done) {
+    if (cur_splice) return Fail(PK_MI355_E_INVALID, "empty network");
+    to_rows();
+  }
+  if (want_tail && !tail_done) {
+    if (cur_dim > 8192) return Fail(PK_MI355_E_INVALID, "output wider than 8192 is not supported");
+    Scoped t(timer, PK_MI355_K_TAIL, stream);
+    LaunchTail(kTailLoglik, cur, cur_ld, rows, cur_dim, blob + am->logprior_off, scale, tail_out,
+               tail_ld, stream);
+  }
+  if (res) { res->data = cur; res->ld = cur_ld; res->dim = cur_dim; }
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) return Fail(PK_MI355_E_DEVICE, "kernel launch failed: %s", hipGetErrorString(le));
+  return 0;
+}
+
+}  // namespace
+
+// Single-utterance workspace used by pk_decodable_init / nnet_propagate.
+struct Workspace {
+  ExecBufs exec;
+  float *d_feats = nullptr;  int64_t feats_cap = 0;     // frame-major host upload
+  float *d_yt = nullptr;     int64_t yt_ld = 0;          // [feat_dim][yt_ld]
+  float *d_out = nullptr;    int64_t out_cap = 0;        // [rows][num_pdfs]
+  hipStream_t stream = nullptr;
+};
+
+namespace {
+
+constexpr int64_t kSingleChunk = 4096;   // frames per pass of the single-utterance path
+
+int EnsureWorkspace(pk_mi355_am *am, int64_t frames, int width) {
+  if (!am->ws) {
+    am->ws = new Workspace();
+    HIP_TRY(hipStreamCreate(&am->ws->stream));
+    int rc = AllocExec(am, kSingleChunk, &am->ws->exec);
+    if (rc) return rc;
+  }
+  Workspace *w = am->ws;
+  const int64_t need_feats = frames * width;
+  if (need_feats > w->feats_cap) {
+    hipFree(w->d_feats);
+    w->feats_cap = need_feats;
+    HIP_TRY(hipMalloc(&w->d_feats, sizeof(float) * w->feats_cap));
+  }
+  const int64_t pad = am->left + am->right;
+  const int64_t need_ld = RoundUp(frames + pad, kSingleChunk) + 256;
+  if (am->feat_dim > 0 && need_ld > w->yt_ld) {
+    hipFree(w->d_yt);
+    w->yt_ld = need_ld;
+    HIP_TRY(hipMalloc(&w->d_yt, sizeof(float) * w->yt_ld * am->feat_dim));
+    HIP_TRY(hipMemset(w->d_yt, 0, sizeof(float) * w->yt_ld * am->feat_dim));
+  }
+  const int64_t need_out = frames * std::max(am->output_dim, 1);
+  if (need_out > w->out_cap) {
+    hipFree(w->d_out);
+    w->out_cap = need_out;
+    HIP_TRY(hipMalloc(&w->d_out, sizeof(float) * w->out_cap));
+  }
+  return 0;
+}
+
+void FreeWorkspace(Workspace *w) {
+  if (!w) return;
+  FreeExec(&w->exec);
+  hipFree(w->d_feats);
+  hipFree(w->d_yt);
+  hipFree(w->d_out);
+  if (w->stream) hipStreamDestroy(w->stream);
+  delete w;
+}
+
+int ResizeHostMatrix(pk_matrix_t *m, int nrow, int ncol) {
+  const size_t total = (size_t)nrow * ncol;
+  float *p = nullptr;
+  if (total > 0) {
+    p = static_cast<float *>(realloc(m->data, sizeof(float) * total));   // matrix.cc:84-97
+    if (!p) return Fail(PK_MI355_E_INVALID, "out of host memory");
+  } else {
+    free(m->data);
+  }
+  m->data = p;
+  m->nrow = nrow;
+  m->ncol = ncol;
+  return 0;
+}
+
+}  // namespace
+
+// ================================================================== C ABI
+
+extern "C" {
+
+const char *pk_mi355_last_error(void) { return g_err; }
+const char *pk_mi355_version(void) { return "pk_mi355 0.1 (gfx950)"; }
+
+int pk_mi355_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int pk_mi355_set_device(int device) {
+  int rc = UseDevice(device);
+  if (rc == 0) g_device = device;
+  return rc;
+}
+
+// ------------------------------------------------------------------ model
+
+pk_mi355_am_t *pk_mi355_am_create(void) {
+  pk_mi355_am *am = new pk_mi355_am();
+  am->device = g_device;
+  return am;
+}
+
+void pk_mi355_am_destroy(pk_mi355_am_t *am) {
+  if (!am) return;
+  hipSetDevice(am->device);
+  FreeWorkspace(am->ws);
+  hipFree(am->d_blob);
+  delete am;
+}
+
+int pk_mi355_am_add_linear(pk_mi355_am_t *am, int in_dim, int out_dim, const float *W,
+                           const float *b) {
+  if (!am || am->finalized) return Fail(PK_MI355_E_STATE, "model is finalized");
+  if (in_dim <= 0 || out_dim <= 0 || !W || !b) return Fail(PK_MI355_E_INVALID, "bad linear layer");
+  HostLayer L;
+  L.type = PK_NNET_LINEAR_LAYER;
+  L.in_dim = in_dim;
+  L.out_dim = out_dim;
+  L.W.assign(W, W + (size_t)in_dim * out_dim);
+  L.b.assign(b, b + out_dim);
+  am->layers.push_back(std::move(L));
+  return 0;
+}
+
+int pk_mi355_am_add_layer(pk_mi355_am_t *am, int layer_type) {
+  if (!am || am->finalized) return Fail(PK_MI355_E_STATE, "model is finalized");
+  if (layer_type != PK_NNET_RELU_LAYER && layer_type != PK_NNET_NORMALIZE_LAYER &&
+      layer_type != PK_NNET_SOFTMAX_LAYER)   // nnet.cc:106-127 accepts only kinds 0..3
+    return Fail(PK_MI355_E_INVALID, "unexpected layer type: %d", layer_type);
+  HostLayer L;
+  L.type = layer_type;
+  am->layers.push_back(L);
+  return 0;
+}
+
+int pk_mi355_am_finalize(pk_mi355_am_t *am, const float *prior, int num_pdfs, int left_context,
+                         int right_context, const int32_t *tid2pdf, int num_tids) {
+  if (!am || am->finalized) return Fail(PK_MI355_E_STATE, "model already finalized");
+  if (left_context < 0 || right_context < 0) return Fail(PK_MI355_E_INVALID, "negative context");
+  int rc = UseDevice(am->device);
+  if (rc) return rc;
+
+  // dimension chain
+  int first_in = 0, dim = 0;
+  am->lin.clear();
+  am->flops_per_frame = 0;
+  size_t off = 0;
+  int max_pad = 0;
+  for (auto &L : am->layers) {
+    if (L.type != PK_NNET_LINEAR_LAYER) continue;
+    if (first_in == 0) { first_in = L.in_dim; }
+    else if (L.in_dim != dim)
+      return Fail(PK_MI355_E_INVALID, "layer dimension mismatch: %d after %d", L.in_dim, dim);
+    dim = L.out_dim;
+    DevLinear D;
+    D.K = L.in_dim; D.N = L.out_dim;
+    D.Kpad = (int)RoundUp(D.K, kBK);
+    D.Npad = (int)RoundUp(D.N, kTile);
+    D.wt_off = off; off += (size_t)D.Kpad * D.Npad;
+    D.b_off = off;  off += D.Npad;
+    am->lin.push_back(D);
+    am->flops_per_frame += 2.0 * D.K * D.N;
+    max_pad = std::max(max_pad, D.Npad);
+    max_pad = std::max(max_pad, (int)RoundUp(D.K, kTile));
+  }
+  if (am->lin.empty()) {
+    // layer-only networks (the nnet_test.cc micro-tests): the width is the pdf count
+    if (num_pdfs <= 0) return Fail(PK_MI355_E_INVALID, "cannot infer the width of a network without linear layers");
+    first_in = dim = num_pdfs;
+    max_pad = (int)RoundUp(dim, kTile);
+  }
+  if (num_pdfs > 0 && num_pdfs != dim)
+    return Fail(PK_MI355_E_INVALID, "num_pdfs = %d but the network outputs %d", num_pdfs, dim);
+  am->input_dim = first_in;
+  am->output_dim = dim;
+  am->num_pdfs = dim;
+  am->left = left_context;
+  am->right = right_context;
+  const int ctx = left_context + right_context + 1;
+  if (first_in % ctx != 0)
+    return Fail(PK_MI355_E_INVALID, "input width %d is not a multiple of the context %d", first_in, ctx);
+  am->feat_dim = first_in / ctx;
+  am->max_dim_pad = max_pad;
+  am->logprior_off = off;
+  off += RoundUp(dim, 4);
+  am->blob_floats = off;
+
+  // pack: W^T zero-padded to [Kpad][Npad] (nnet.cc:16-17 keeps the transpose),
+  // bias padded, log prior (am.cc:43: logf of the probabilities)
+  std::vector<float> blob(off, 0.0f);
+  size_t li = 0;
+  for (auto &L : am->layers) {
+    if (L.type != PK_NNET_LINEAR_LAYER) continue;
+    const DevLinear &D = am->lin[li++];
+    float *wt = blob.data() + D.wt_off;
+    for (int o = 0; o < D.N; ++o)
+      for (int k = 0; k < D.K; ++k) wt[(size_t)k * D.Npad + o] = L.W[(size_t)o * D.K + k];
+    memcpy(blob.data() + D.b_off, L.b.data(), sizeof(float) * D.N);
+  }
+  for (int i = 0; i < dim; ++i)
+    blob[am->logprior_off + i] = prior ? logf(prior[i]) : 0.0f;
+  HIP_TRY(hipMalloc(&am->d_blob, sizeof(float) * off));
+  HIP_TRY(hipMemcpy(am->d_blob, blob.data(), sizeof(float) * off, hipMemcpyHostToDevice));
+
+  am->tid2pdf.clear();
+  if (tid2pdf && num_tids > 0) am->tid2pdf.assign(tid2pdf, tid2pdf + num_tids);
+  am->finalized = true;
+  return 0;
+}
+
+int pk_mi355_am_read(pk_mi355_am_t *am, const char *nnet_path, const char *prior_path,
+                     const char *tid2pdf_path, int left_context, int right_context,
+                     int num_pdfs) {
+  if (!am || am->finalized) return Fail(PK_MI355_E_STATE, "model already finalized");
+  FileBuf f;
+  int rc = f.Open(nnet_path);
+  if (rc) return rc;
+  int32_t sec, num_layers;
+  if (!f.Tag("NNT0") || !f.I32(&sec) || !f.I32(&num_layers) || sec != 4)
+    return Fail(PK_MI355_E_IO, "NNT0 section expected in %s", nnet_path);
+  for (int l = 0; l < num_layers; ++l) {
+    int32_t type;
+    if (!f.Tag("LAY0") || !f.I32(&sec) || !f.I32(&type))
+      return Fail(PK_MI355_E_IO, "LAY0 section expected in %s", nnet_path);
+    if (sec != 4)    // nnet.cc:94-101
+      return Fail(PK_MI355_E_IO, "read_layer: section_size == 4 expected, but %d found (%s)", sec, nnet_path);
+    if (type == PK_NNET_LINEAR_LAYER) {
+      int32_t rows, cols;
+      if (!f.Tag("MAT0") || !f.I32(&sec) || !f.I32(&rows) || !f.I32(&cols) || rows <= 0 || cols <= 0)
+        return Fail(PK_MI355_E_IO, "MAT0 section expected in %s", nnet_path);
+      std::vector<float> W((size_t)rows * cols), row, bias;
+      for (int r = 0; r < rows; ++r) {
+        if ((rc = f.Vec(&row))) return rc;
+        if ((int)row.size() != cols)
+          return Fail(PK_MI355_E_IO, "Matrix::Read: row dim %d expected, but %d found: %s", cols, (int)row.size(), nnet_path);
+        memcpy(&W[(size_t)r * cols], row.data(), sizeof(float) * cols);
+      }
+      if ((rc = f.Vec(&bias))) return rc;
+      if ((int)bias.size() != rows) return Fail(PK_MI355_E_IO, "bias dimension mismatch in %s", nnet_path);
+      if ((rc = pk_mi355_am_add_linear(am, cols, rows, W.data(), bias.data()))) return rc;
+    } else {
+      if ((rc = pk_mi355_am_add_layer(am, type)))
+        return Fail(PK_MI355_E_IO, "read_layer: unexpected layer type: %d (%s)", type, nnet_path);
+    }
+  }
+  std::vector<float> prior;
+  FileBuf pf;
+  if ((rc = pf.Open(prior_path)) || (rc = pf.Vec(&prior))) return rc;
+  std::vector<int32_t> tid;
+  if (tid2pdf_path) {
+    FileBuf tf;
+    if ((rc = tf.Open(tid2pdf_path)) || (rc = tf.Vec(&tid))) return rc;
+  }
+  if ((int)prior.size() != num_pdfs)
+    return Fail(PK_MI355_E_INVALID, "prior has %d entries, num_pdfs = %d", (int)prior.size(), num_pdfs);
+  return pk_mi355_am_finalize(am, prior.data(), num_pdfs, left_context, right_context,
+                              tid.empty() ? nullptr : tid.data(), (int)tid.size());
+}
+
+int pk_mi355_am_num_pdfs(const pk_mi355_am_t *am) { return am ? am->num_pdfs : 0; }
+int pk_mi355_am_input_dim(const pk_mi355_am_t *am) { return am ? am->input_dim : 0; }
+int pk_mi355_am_transition_to_pdf(const pk_mi355_am_t *am, int trans_id) {
+  if (am->tid2pdf.empty()) return trans_id;
+  return am->tid2pdf[trans_id];
+}
+void *pk_mi355_am_blob_device_ptr(pk_mi355_am_t *am) { return am ? am->d_blob : nullptr; }
+size_t pk_mi355_am_blob_bytes(const pk_mi355_am_t *am) { return am ? am->blob_floats * sizeof(float) : 0; }
+double pk_mi355_am_flops_per_frame(const pk_mi355_am_t *am) { return am ? am->flops_per_frame : 0; }
+
+int pk_mi355_nnet_propagate(pk_mi355_am_t *am, const pk_matrix_t *in, pk_matrix_t *out) {
+  if (!am || !am->finalized) return Fail(PK_MI355_E_STATE, "model not finalized");
+  if (!in || !out || in->nrow != am->input_dim)
+    return Fail(PK_MI355_E_INVALID, "input has %d rows, the network expects %d", in ? in->nrow : -1, am->input_dim);
+  int rc = UseDevice(am->device);
+  if (rc) return rc;
+  const int T = in->ncol, D = in->nrow;
+  if ((rc = ResizeHostMatrix(out, am->output_dim, T))) return rc;
+  if (T == 0) return 0;
+  if ((rc = EnsureWorkspace(am, T, std::max(D, am->output_dim)))) return rc;
+  Workspace *w = am->ws;
+  HIP_TRY(hipMemcpyAsync(w->d_feats, in->data, sizeof(float) * (size_t)T * D, hipMemcpyHostToDevice, w->stream));
+  for (int64_t r0 = 0; r0 < T; r0 += kSingleChunk) {
+    const int rows = (int)std::min<int64_t>(kSingleChunk, T - r0);
+    LaunchTransposeToCols(w->d_feats + r0 * D, D, rows, D, w->exec.in, w->exec.rows_cap, w->stream);
+    ExecResult res;
+    if ((rc = RunLayers(am, w->exec, nullptr, 0, 0, rows, false, 1.0f, nullptr, 0, w->stream, nullptr, &res)))
+      return rc;
+    HIP_TRY(hipMemcpy2DAsync(out->data + r0 * am->output_dim, sizeof(float) * am->output_dim, res.data,
+                             sizeof(float) * res.ld, sizeof(float) * am->output_dim, rows,
+                             hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ decodable
+
+void pk_decodable_init(pk_decodable_t *self, pk_mi355_am_t *am, float prob_scale,
+                       const pk_matrix_t *feats) {
+  self->log_prob.ncol = 0;
+  self->log_prob.nrow = 0;
+  self->log_prob.data = nullptr;
+  self->am = am;
+  if (!am || !am->finalized) { Fail(PK_MI355_E_STATE, "model not finalized"); return; }
+  if (!feats || feats->nrow != am->feat_dim) {
+    Fail(PK_MI355_E_INVALID, "features have %d rows, the model expects %d", feats ? feats->nrow : -1, am->feat_dim);
+    return;
+  }
+  if (UseDevice(am->device)) return;
+  const int T = feats->ncol, D = feats->nrow, N = am->num_pdfs;
+  if (T <= 0) return;
+  if (EnsureWorkspace(am, T, D)) return;
+  Workspace *w = am->ws;
+  auto dev_fail = [&](hipError_t e) { Fail(PK_MI355_E_DEVICE, "HIP failure in pk_decodable_init: %s", hipGetErrorString(e)); };
+  hipError_t e = hipMemcpyAsync(w->d_feats, feats->data, sizeof(float) * (size_t)T * D, hipMemcpyHostToDevice, w->stream);
+  if (e != hipSuccess) { dev_fail(e); return; }
+  LaunchPadTranspose(w->d_feats, T, D, am->left, am->right, w->d_yt, w->yt_ld, 0, w->stream);
+  for (int64_t r0 = 0; r0 < T; r0 += kSingleChunk) {
+    const int rows = (int)std::min<int64_t>(kSingleChunk, T - r0);
+    if (RunLayers(am, w->exec, w->d_yt + r0, w->yt_ld, D, rows, true, prob_scale, w->d_out + r0 * N, N,
+                  w->stream, nullptr, nullptr))
+      return;
+  }
+  float *host = static_cast<float *>(malloc(sizeof(float) * (size_t)T * N));   // util.cc:58-68 pk_alloc
+  if (!host) { Fail(PK_MI355_E_INVALID, "out of host memory"); return; }
+  e = hipMemcpyAsync(host, w->d_out, sizeof(float) * (size_t)T * N, hipMemcpyDeviceToHost, w->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
+  if (e != hipSuccess) { free(host); dev_fail(e); return; }
+  self->log_prob.ncol = T;
+  self->log_prob.nrow = N;
+  self->log_prob.data = host;
+}
+
+void pk_decodable_destroy(pk_decodable_t *self) {
+  free(self->log_prob.data);          // matrix.cc:123-128
+  self->log_prob.data = nullptr;
+  self->log_prob.nrow = 0;
+  self->log_prob.ncol = 0;
+  self->am = nullptr;
+}
+
+float pk_decodable_loglikelihood(pk_decodable_t *self, int frame, int trans_id) {
+  const int pdf = pk_mi355_am_transition_to_pdf(self->am, trans_id);
+  return self->log_prob.data[(size_t)frame * self->log_prob.nrow + pdf];
+}
+
+bool pk_decodable_islastframe(pk_decodable_t *self, int frame) {
+  return frame == self->log_prob.ncol - 1;
+}
+
+}  // extern "C"
+
+// ================================================================== front-end + batch
+
+struct pk_mi355_batch {
+  pk_mi355_am *am = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  Timer timer;
+  FrontendTables *d_tables = nullptr;
+  float *d_global = nullptr;
+  int max_utts = 0;
+  int64_t max_samples = 0, max_frames = 0, max_cols = 0;
+  int64_t chunk = 8192;
+  // PCM
+  float *d_wave = nullptr;          // owned float buffer
+  int16_t *d_wave_i16 = nullptr;    // owned int16 buffer
+  const float *wave_f32 = nullptr;  // what the kernels read (owned or external)
+  const int16_t *wave_i16 = nullptr;
+  // per-utterance placement
+  int num_utts = 0;
+  int max_T = 0;
+  int64_t total_frames = 0, total_cols = 0;
+  std::vector<int64_t> h_wave_off, h_raw_base, h_pad_base;
+  std::vector<int32_t> h_T;
+  int64_t *d_wave_off = nullptr, *d_raw_base = nullptr, *d_pad_base = nullptr;
+  int32_t *d_T = nullptr;
+  // stages
+  float *d_raw = nullptr;   // [max_frames][40]
+  float *d_yt = nullptr;    // [feat_dim][ldy]
+  int64_t ldy = 0;
+  float *d_ll = nullptr;    // [max_cols][num_pdfs]
+  ExecBufs exec;
+  bool scored = false;
+};
+
+namespace {
+
+int SetLayout(pk_mi355_batch *b, const int *num_samples, int num_utts) {
+  if (num_utts < 0 || num_utts > b->max_utts) return Fail(PK_MI355_E_INVALID, "too many utterances (%d > %d)", num_utts, b->max_utts);
+  const int pad = b->am->left + b->am->right;
+  int64_t woff = 0, raw = 0, col = 0;
+  b->h_wave_off.resize(num_utts); b->h_raw_base.resize(num_utts);
+  b->h_pad_base.resize(num_utts); b->h_T.resize(num_utts);
+  b->max_T = 0;
+  for (int u = 0; u < num_utts; ++u) {
+    if (num_samples[u] < 0) return Fail(PK_MI355_E_INVALID, "negative sample count");
+    const int T = pk_mi355_num_frames(num_samples[u]);
+    b->h_wave_off[u] = woff; b->h_raw_base[u] = raw; b->h_pad_base[u] = col; b->h_T[u] = T;
+    woff += num_samples[u];
+    raw += T;
+    col += T > 0 ? T + pad : 0;
+    b->max_T = std::max(b->max_T, T);
+  }
+  if (woff > b->max_samples) return Fail(PK_MI355_E_INVALID, "too many samples (%lld > %lld)", (long long)woff, (long long)b->max_samples);
+  if (raw > b->max_frames || RoundUp(col, kTile) > b->max_cols) return Fail(PK_MI355_E_INVALID, "frame capacity exceeded");
+  b->num_utts = num_utts;
+  b->total_frames = raw;
+  b->total_cols = col;
+  b->scored = false;
+  if (num_utts == 0) return 0;
+  HIP_TRY(hipMemcpyAsync(b->d_wave_off, b->h_wave_off.data(), sizeof(int64_t) * num_utts, hipMemcpyHostToDevice, b->stream));
+  HIP_TRY(hipMemcpyAsync(b->d_raw_base, b->h_raw_base.data(), sizeof(int64_t) * num_utts, hipMemcpyHostToDevice, b->stream));
+  HIP_TRY(hipMemcpyAsync(b->d_pad_base, b->h_pad_base.data(), sizeof(int64_t) * num_utts, hipMemcpyHostToDevice, b->stream));
+  HIP_TRY(hipMemcpyAsync(b->d_T, b->h_T.data(), sizeof(int32_t) * num_utts, hipMemcpyHostToDevice, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));   // the host vectors may be reused right away
+  return 0;
+}
+
+int64_t TotalSamples(const int *num_samples, int n) {
+  int64_t s = 0;
+  for (int i = 0; i < n; ++i) s += num_samples[i];
+  return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pk_mi355_num_frames(int num_samples) {      // fbank.cc:35-42
+  if (num_samples < kFrameLength) return 0;
+  return 1 + (num_samples - kFrameLength) / kFrameShift;
+}
+
+pk_mi355_batch_t *pk_mi355_batch_create(pk_mi355_am_t *am, const float *global_stats41,
+                                        int max_utts, int64_t max_total_samples) {
+  if (!am || !am->finalized) { Fail(PK_MI355_E_STATE, "model not finalized"); return nullptr; }
+  if (am->feat_dim != kNumBins) { Fail(PK_MI355_E_INVALID, "the front-end produces %d-dim features, the model expects %d", kNumBins, am->feat_dim); return nullptr; }
+  if (!global_stats41 || max_utts <= 0 || max_total_samples <= 0) { Fail(PK_MI355_E_INVALID, "bad batch capacity"); return nullptr; }
+  if (UseDevice(am->device)) return nullptr;
+  pk_mi355_batch *b = new pk_mi355_batch();
+  b->am = am;
+  b->device = am->device;
+  b->max_utts = max_utts;
+  b->max_samples = max_total_samples;
+  if (const char *c = getenv("PK_MI355_CHUNK")) {
+    long v = atol(c);
+    if (v >= kTile) b->chunk = RoundUp(v, kTile);
+  }
+  const int pad = am->left + am->right;
+  b->max_frames = max_total_samples / kFrameShift + max_utts;
+  b->max_cols = RoundUp(b->max_frames + (int64_t)max_utts * pad, kTile);
+  b->chunk = std::min<int64_t>(b->chunk, b->max_cols);
+  b->ldy = RoundUp(b->max_cols, b->chunk) + 256;
+  FrontendTables host;
+  bool ok = BuildFrontendTables(&host) == 0;
+  auto chk = [&](hipError_t e) { if (e != hipSuccess && ok) { ok = false; Fail(PK_MI355_E_DEVICE, "batch_create: %s", hipGetErrorString(e)); } };
+  if (!ok) Fail(PK_MI355_E_INVALID, "front-end table construction failed");
+  chk(hipStreamCreate(&b->stream));
+  chk(hipMalloc(&b->d_tables, sizeof(FrontendTables)));
+  if (ok) chk(hipMemcpy(b->d_tables, &host, sizeof(FrontendTables), hipMemcpyHostToDevice));
+  chk(hipMalloc(&b->d_global, sizeof(float) * (kNumBins + 1)));
+  if (ok) chk(hipMemcpy(b->d_global, global_stats41, sizeof(float) * (kNumBins + 1), hipMemcpyHostToDevice));
+  chk(hipMalloc(&b->d_wave_off, sizeof(int64_t) * max_utts));
+  chk(hipMalloc(&b->d_raw_base, sizeof(int64_t) * max_utts));
+  chk(hipMalloc(&b->d_pad_base, sizeof(int64_t) * max_utts));
+  chk(hipMalloc(&b->d_T, sizeof(int32_t) * max_utts));
+  chk(hipMalloc(&b->d_raw, sizeof(float) * b->max_frames * kNumBins));
+  chk(hipMalloc(&b->d_yt, sizeof(float) * b->ldy * kNumBins));
+  if (ok) chk(hipMemset(b->d_yt, 0, sizeof(float) * b->ldy * kNumBins));
+  chk(hipMalloc(&b->d_ll, sizeof(float) * b->max_cols * am->num_pdfs));
+  if (ok && AllocExec(am, b->chunk, &b->exec)) ok = false;
+  if (!ok) { pk_mi355_batch_destroy(b); return nullptr; }
+  return b;
+}
+
+void pk_mi355_batch_destroy(pk_mi355_batch_t *b) {
+  if (!b) return;
+  hipSetDevice(b->device);
+  if (b->stream) hipStreamSynchronize(b->stream);
+  FreeExec(&b->exec);
+  hipFree(b->d_tables); hipFree(b->d_global);
+  hipFree(b->d_wave); hipFree(b->d_wave_i16);
+  hipFree(b->d_wave_off); hipFree(b->d_raw_base); hipFree(b->d_pad_base); hipFree(b->d_T);
+  hipFree(b->d_raw); hipFree(b->d_yt); hipFree(b->d_ll);
+  if (b->stream) hipStreamDestroy(b->stream);
+  delete b;
+}
+
+int pk_mi355_batch_set_waves(pk_mi355_batch_t *b, const pk_vector_t *waves, int num_utts) {
+  if (!b || !waves) return Fail(PK_MI355_E_INVALID, "null argument");
+  int rc = UseDevice(b->device);
+  if (rc) return rc;
+  std::vector<int> ns(num_utts);
+  for (int u = 0; u < num_utts; ++u) ns[u] = waves[u].dim;
+  if (TotalSamples(ns.data(), num_utts) > b->max_samples) return Fail(PK_MI355_E_INVALID, "too many samples");
+  if (!b->d_wave) HIP_TRY(hipMalloc(&b->d_wave, sizeof(float) * b->max_samples));
+  int64_t off = 0;
+  for (int u = 0; u < num_utts; ++u) {
+    if (ns[u] > 0)
+      HIP_TRY(hipMemcpyAsync(b->d_wave + off, waves[u].data, sizeof(float) * ns[u], hipMemcpyHostToDevice, b->stream));
+    off += ns[u];
+  }
+  b->wave_f32 = b->d_wave;
+  b->wave_i16 = nullptr;
+  return SetLayout(b, ns.data(), num_utts);
+}
+
+int pk_mi355_batch_set_waves_i16(pk_mi355_batch_t *b, const int16_t *samples, const int *num_samples,
+                                 int num_utts) {
+  if (!b || !samples || !num_samples) return Fail(PK_MI355_E_INVALID, "null argument");
+  int rc = UseDevice(b->device);
+  if (rc) return rc;
+  const int64_t total = TotalSamples(num_samples, num_utts);
+  if (total > b->max_samples) return Fail(PK_MI355_E_INVALID, "too many samples");
+  if (!b->d_wave_i16) HIP_TRY(hipMalloc(&b->d_wave_i16, sizeof(int16_t) * b->max_samples));
+  if (total > 0)
+    HIP_TRY(hipMemcpyAsync(b->d_wave_i16, samples, sizeof(int16_t) * total, hipMemcpyHostToDevice, b->stream));
+  b->wave_i16 = b->d_wave_i16;
+  b->wave_f32 = nullptr;
+  return SetLayout(b, num_samples, num_utts);
+}
+
+int pk_mi355_batch_set_waves_device(pk_mi355_batch_t *b, const float *d_samples, const int *num_samples,
+                                    int num_utts) {
+  if (!b || !d_samples || !num_samples) return Fail(PK_MI355_E_INVALID, "null argument");
+  int rc = UseDevice(b->device);
+  if (rc) return rc;
+  b->wave_f32 = d_samples;
+  b->wave_i16 = nullptr;
+  return SetLayout(b, num_samples, num_utts);
+}
+
+int pk_mi355_batch_score(pk_mi355_batch_t *b, float prob_scale, int sync) {
+  if (!b) return Fail(PK_MI355_E_INVALID, "null batch");
+  if (!b->wave_f32 && !b->wave_i16) return Fail(PK_MI355_E_STATE, "no waves set");
+  int rc = UseDevice(b->device);
+  if (rc) return rc;
+  pk_mi355_am *am = b->am;
+  Timer *tm = b->timer.enabled ? &b->timer : nullptr;
+  if (tm) tm->Reset();
+  if (b->num_utts == 0 || b->total_frames == 0) { b->scored = true; return 0; }
+  UttLayout lay{b->d_wave_off, b->d_T, b->d_raw_base, b->d_pad_base};
+  {
+    Scoped t(tm, PK_MI355_K_FBANK, b->stream);
+    LaunchFbank(b->wave_f32, b->wave_i16, lay, b->num_utts, b->max_T, b->d_tables, b->d_raw, b->stream);
+  }
+  {
+    Scoped t(tm, PK_MI355_K_CMVN, b->stream);
+    LaunchCmvn(b->d_raw, lay, b->num_utts, b->d_global, am->left, am->right, b->d_yt, b->ldy, b->stream);
+  }
+  // Rows of the spliced operand = padded columns; row r of utterance u (r in
+  // [pad_base, pad_base + T)) is its frame r - pad_base.  The few rows that
+  // straddle two utterances are computed and ignored.
+  const int N = am->num_pdfs;
+  for (int64_t c0 = 0; c0 < b->total_cols; c0 += b->chunk) {
+    const int rows = (int)std::min<int64_t>(b->chunk, b->total_cols - c0);
+    rc = RunLayers(am, b->exec, b->d_yt + c0, b->ldy, kNumBins, rows, true, prob_scale,
+                   b->d_ll + c0 * N, N, b->stream, tm, nullptr);
+    if (rc) return rc;
+  }
+  b->scored = true;
+  if (sync) HIP_TRY(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
+int pk_mi355_batch_synchronize(pk_mi355_batch_t *b) {
+  if (!b) return Fail(PK_MI355_E_INVALID, "null batch");
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
+int pk_mi355_batch_num_utts(const pk_mi355_batch_t *b) { return b ? b->num_utts : 0; }
+int pk_mi355_batch_num_frames(const pk_mi355_batch_t *b, int utt) {
+  return (b && utt >= 0 && utt < b->num_utts) ? b->h_T[utt] : 0;
+}
+int64_t pk_mi355_batch_total_frames(const pk_mi355_batch_t *b) { return b ? b->total_frames : 0; }
+
+const float *pk_mi355_batch_loglik_device(const pk_mi355_batch_t *b, int utt) {
+  if (!b || utt < 0 || utt >= b->num_utts) return nullptr;
+  return b->d_ll + b->h_pad_base[utt] * b->am->num_pdfs;
+}
+
+int pk_mi355_batch_fetch(pk_mi355_batch_t *b, int utt, pk_decodable_t *out) {
+  if (!b || !out || utt < 0 || utt >= b->num_utts) return Fail(PK_MI355_E_INVALID, "bad utterance index");
+  if (!b->scored) return Fail(PK_MI355_E_STATE, "batch not scored");
+  int rc = UseDevice(b->device);
+  if (rc) return rc;
+  const int T = b->h_T[utt], N = b->am->num_pdfs;
+  out->am = b->am;
+  out->log_prob.ncol = 0; out->log_prob.nrow = 0; out->log_prob.data = nullptr;
+  if (T == 0) return 0;
+  float *host = static_cast<float *>(malloc(sizeof(float) * (size_t)T * N));
+  if (!host) return Fail(PK_MI355_E_INVALID, "out of host memory");
+  hipError_t e = hipMemcpyAsync(host, pk_mi355_batch_loglik_device(b, utt), sizeof(float) * (size_t)T * N,
+                                hipMemcpyDeviceToHost, b->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+  if (e != hipSuccess) { free(host); return Fail(PK_MI355_E_DEVICE, "fetch: %s", hipGetErrorString(e)); }
+  out->log_prob.ncol = T; out->log_prob.nrow = N; out->log_prob.data = host;
+  return 0;
+}
+
+int pk_mi355_batch_fetch_fbank(pk_mi355_batch_t *b, int utt, float *out) {
+  if (!b || !out || utt < 0 || utt >= b->num_utts) return Fail(PK_MI355_E_INVALID, "bad utterance index");
+  if (!b->scored) return Fail(PK_MI355_E_STATE, "batch not scored");
+  const int T = b->h_T[utt];
+  if (T == 0) return 0;
+  HIP_TRY(hipMemcpyAsync(out, b->d_raw + b->h_raw_base[utt] * kNumBins, sizeof(float) * (size_t)T * kNumBins,
+                         hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
+int pk_mi355_batch_fetch_cmvn(pk_mi355_batch_t *b, int utt, float *out) {
+  if (!b || !out || utt < 0 || utt >= b->num_utts) return Fail(PK_MI355_E_INVALID, "bad utterance index");
+  if (!b->scored) return Fail(PK_MI355_E_STATE, "batch not scored");
+  const int T = b->h_T[utt];
+  if (T == 0) return 0;
+  std::vector<float> tmp((size_t)kNumBins * T);
+  HIP_TRY(hipMemcpy2DAsync(tmp.data(), sizeof(float) * T, b->d_yt + b->h_pad_base[utt] + b->am->left,
+                           sizeof(float) * b->ldy, sizeof(float) * T, kNumBins, hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  for (int t = 0; t < T; ++t)
+    for (int d = 0; d < kNumBins; ++d) out[(size_t)t * kNumBins + d] = tmp[(size_t)d * T + t];
+  return 0;
+}
+
+void *pk_mi355_batch_stream(pk_mi355_batch_t *b) { return b ? (void *)b->stream : nullptr; }
+
+int pk_mi355_batch_enable_timing(pk_mi355_batch_t *b, int enable) {
+  if (!b) return Fail(PK_MI355_E_INVALID, "null batch");
+  b->timer.enabled = enable != 0;
+  if (!enable) b->timer.Reset();
+  return 0;
+}
+
+int pk_mi355_batch_get_timing(pk_mi355_batch_t *b, float ms[PK_MI355_K_COUNT], int launches[PK_MI355_K_COUNT]) {
+  if (!b) return Fail(PK_MI355_E_INVALID, "null batch");
+  for (int k = 0; k < PK_MI355_K_COUNT; ++k) { ms[k] = 0; launches[k] = 0; }
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  for (auto &r : b->timer.recs) {
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+    ms[r.kind] += t;
+    launches[r.kind] += 1;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ single-utterance front-end
+
+int pk_mi355_fbank_compute(const pk_vector_t *wave, pk_matrix_t *out) {
+  if (!wave || !out) return Fail(PK_MI355_E_INVALID, "null argument");
+  int rc = UseDevice(g_device);
+  if (rc) return rc;
+  const int T = pk_mi355_num_frames(wave->dim);
+  if (T == 0) return ResizeHostMatrix(out, 0, 0);          // fbank.cc:272-273
+  if ((rc = ResizeHostMatrix(out, kNumBins, T))) return rc;
+  FrontendTables host;
+  if (BuildFrontendTables(&host)) return Fail(PK_MI355_E_INVALID, "front-end table construction failed");
+  FrontendTables *d_tab = nullptr;
+  float *d_wave = nullptr, *d_raw = nullptr;
+  int64_t *d_i64 = nullptr;
+  int32_t *d_T = nullptr;
+  int64_t zeros[2] = {0, 0};
+  int32_t hT = T;
+  int ret = 0;
+  hipError_t e = hipSuccess;
+  auto step = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+  step(hipMalloc(&d_tab, sizeof(FrontendTables)));
+  step(hipMalloc(&d_wave, sizeof(float) * wave->dim));
+  step(hipMalloc(&d_raw, sizeof(float) * (size_t)T * kNumBins));
+  step(hipMalloc(&d_i64, sizeof(int64_t) * 2));
+  step(hipMalloc(&d_T, sizeof(int32_t)));
+  if (e == hipSuccess) {
+    step(hipMemcpy(d_tab, &host, sizeof(FrontendTables), hipMemcpyHostToDevice));
+    step(hipMemcpy(d_wave, wave->data, sizeof(float) * wave->dim, hipMemcpyHostToDevice));
+    step(hipMemcpy(d_i64, zeros, sizeof(zeros), hipMemcpyHostToDevice));
+    step(hipMemcpy(d_T, &hT, sizeof(hT), hipMemcpyHostToDevice));
+  }
+  if (e == hipSuccess) {
+    UttLayout lay{d_i64, d_T, d_i64 + 1, d_i64 + 1};
+    LaunchFbank(d_wave, nullptr, lay, 1, T, d_tab, d_raw, nullptr);
+    step(hipGetLastError());
+    step(hipMemcpy(out->data, d_raw, sizeof(float) * (size_t)T * kNumBins, hipMemcpyDeviceToHost));
+  }
+  if (e != hipSuccess) ret = Fail(PK_MI355_E_DEVICE, "fbank_compute: %s", hipGetErrorString(e));
+  hipFree(d_tab); hipFree(d_wave); hipFree(d_raw); hipFree(d_i64); hipFree(d_T);
+  return ret;
+}
+
+int pk_mi355_cmvn_apply(const pk_vector_t *global_stats, const pk_matrix_t *raw, pk_matrix_t *out) {
+  if (!global_stats || !raw || !out) return Fail(PK_MI355_E_INVALID, "null argument");
+  if (global_stats->dim != kNumBins + 1 || (raw->ncol > 0 && raw->nrow != kNumBins))
+    return Fail(PK_MI355_E_INVALID, "cmvn expects 41 global stats and 40-dim features");
+  int rc = UseDevice(g_device);
+  if (rc) return rc;
+  const int T = raw->ncol;
+  if ((rc = ResizeHostMatrix(out, T > 0 ? kNumBins : 0, T))) return rc;
+  if (T == 0) return 0;
+  float *d_raw = nullptr, *d_g = nullptr, *d_yt = nullptr;
+  int64_t *d_i64 = nullptr;
+  int32_t *d_T = nullptr;
+  int64_t zeros[2] = {0, 0};
+  int32_t hT = T;
+  const int64_t ld = RoundUp(T, 64);
+  std::vector<float> tmp((size_t)kNumBins * T);
+  hipError_t e = hipSuccess;
+  auto step = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+  step(hipMalloc(&d_raw, sizeof(float) * (size_t)T * kNumBins));
+  step(hipMalloc(&d_g, sizeof(float) * (kNumBins + 1)));
+  step(hipMalloc(&d_yt, sizeof(float) * ld * kNumBins));
+  step(hipMalloc(&d_i64, sizeof(int64_t) * 2));
+  step(hipMalloc(&d_T, sizeof(int32_t)));
+  if (e == hipSuccess) {
+    step(hipMemcpy(d_raw, raw->data, sizeof(float) * (size_t)T * kNumBins, hipMemcpyHostToDevice));
+    step(hipMemcpy(d_g, global_stats->data, sizeof(float) * (kNumBins + 1), hipMemcpyHostToDevice));
+    step(hipMemcpy(d_i64, zeros, sizeof(zeros), hipMemcpyHostToDevice));
+    step(hipMemcpy(d_T, &hT, sizeof(hT), hipMemcpyHostToDevice));
+  }
+  if (e == hipSuccess) {
+    UttLayout lay{d_i64, d_T, d_i64, d_i64 + 1};
+    LaunchCmvn(d_raw, lay, 1, d_g, 0, 0, d_yt, ld, nullptr);
+    step(hipGetLastError());
+    step(hipMemcpy2D(tmp.data(), sizeof(float) * T, d_yt, sizeof(float) * ld, sizeof(float) * T, kNumBins,
+                     hipMemcpyDeviceToHost));
+  }
+  int ret = 0;
+  if (e != hipSuccess) ret = Fail(PK_MI355_E_DEVICE, "cmvn_apply: %s", hipGetErrorString(e));
+  else
+    for (int t = 0; t < T; ++t)
+      for (int d = 0; d < kNumBins; ++d) out->data[(size_t)t * kNumBins + d] = tmp[(size_t)d * T + t];
+  hipFree(d_raw); hipFree(d_g); hipFree(d_yt); hipFree(d_i64); hipFree(d_T);
+  return ret;
+}
+
+}  // extern "C"

@@ -1,0 +1,355 @@
+// frontend.hip -- fbank (window -> 512-point split-radix real FFT -> power ->
+// mel -> log) and sliding-window CMVN for gfx950.
+//
+// Parity strategy: every float expression is evaluated with the same operations
+// in the same order as the reference (fbank.cc, srfft.cc, cmvn.cc), so results
+// are bit-identical wherever IEEE arithmetic is; the file is compiled with
+// -ffp-contract=off so a*b+c is never fused where the reference's x86-64 build
+// does not fuse.  The only non-IEEE step is the final natural log (fbank.cc:245):
+// it is taken in fp64 and rounded once, which reproduces glibc's logf except for
+// rare 1-ULP cases.
+//
+// Execution shape: one 64-lane wavefront per frame (a workgroup IS one wave), the
+// frame lives in LDS, the eight split-radix passes each run <= 64 independent
+// "L" butterflies -- one per lane -- with a wave-level barrier between passes.
+#include <hip/hip_runtime.h>
+
+#include "pk_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace pkmi {
+
+namespace {
+
+constexpr int kWave = 64;
+
+// One split-radix "L" butterfly on points n, n+m/4, n+m/2, n+3m/4 of the block at
+// `base`: srfft.cc:163-173 (radix-2 step), :176-188 (+-j step), :198-222
+// (twiddles).  The reference sweeps each step over the whole block; the quads
+// are disjoint so doing all three steps per quad rounds identically.
+template <int LOGM>
+__device__ __forceinline__ void LButterfly(float *xr, float *xi, int base, int n,
+                                           const float *__restrict__ tw) {
+  constexpr int m = 1 << LOGM, m2 = m / 2, m4 = m / 4, m8 = m / 8;
+  const int i0 = base + n, i1 = i0 + m4, i2 = i0 + m2, i3 = i2 + m4;
+
+  float ar = xr[i0] + xr[i2], br = xr[i0] - xr[i2];
+  float ai = xi[i0] + xi[i2], bi = xi[i0] - xi[i2];
+  float cr = xr[i1] + xr[i3], dr = xr[i1] - xr[i3];
+  float ci = xi[i1] + xi[i3], di = xi[i1] - xi[i3];
+  xr[i0] = ar; xi[i0] = ai; xr[i1] = cr; xi[i1] = ci;
+
+  float r1 = br + di;   // -> xr[i2]
+  float q2 = bi + dr;   // -> xi[i3]
+  float q1 = bi - dr;   // -> xi[i2]
+  float r2 = br - di;   // -> xr[i3]
+
+  if (LOGM >= 3 && n != 0) {
+    if (n == m8) {
+      const float sq = 0.70710678118654752440;   // srfft.cc:41-43, narrowed like `float sqhalf`
+      float t1 = sq * (r1 + q1);
+      q1 = sq * (q1 - r1);
+      r1 = t1;
+      float t2 = sq * (q2 - r2);
+      q2 = -sq * (r2 + q2);
+      r2 = t2;
+    } else if (LOGM >= 4) {
+      const float cn = tw[0 * m4 + n], spcn = tw[1 * m4 + n], smcn = tw[2 * m4 + n];
+      const float c3n = tw[3 * m4 + n], spc3n = tw[4 * m4 + n], smc3n = tw[5 * m4 + n];
+      float t2 = cn * (r1 + q1);
+      float t1 = spcn * r1 + t2;
+      r1 = smcn * q1 + t2;
+      q1 = t1;
+      t2 = c3n * (r2 + q2);
+      t1 = spc3n * r2 + t2;
+      r2 = smc3n * q2 + t2;
+      q2 = t1;
+    }
+  }
+  xr[i2] = r1; xi[i2] = q1; xr[i3] = r2; xi[i3] = q2;
+}
+
+template <int LOGM>
+__device__ __forceinline__ void FftPass(float *xr, float *xi, int lane,
+                                        const FrontendTables *__restrict__ tab) {
+  constexpr int pass = kLogCplx - LOGM;
+  constexpr int q = (1 << LOGM) / 4;        // butterflies per block
+  const int first = tab->pass_start[pass];
+  const int nblk = tab->pass_start[pass + 1] - first;
+  const int b = lane / q, n = lane % q;     // q is a power of two
+  if (b < nblk) {
+    const float *tw = LOGM >= 4 ? tab->tw + tab->tw_off[LOGM] : nullptr;
+    LButterfly<LOGM>(xr, xi, tab->blk_off[first + b], n, tw);
+  }
+  __syncthreads();
+}
+
+// A workgroup of one wave walks frames  t = blockIdx.x, blockIdx.x + gridDim.x, ...
+// of utterance blockIdx.y.
+template <typename SampleT>
+__global__ __launch_bounds__(kWave) void FbankKernel(const SampleT *__restrict__ wave,
+                                                     UttLayout utts,
+                                                     const FrontendTables *__restrict__ tab,
+                                                     float *__restrict__ raw) {
+  __shared__ float s_x[kFrameLength];       // DC-removed samples (pre-emphasis neighbour)
+  __shared__ float s_re[kFftCplx];
+  __shared__ float s_im[kFftCplx];
+  __shared__ float s_pow[kFftCplx + 1];
+  __shared__ float s_sum;
+
+  const int lane = threadIdx.x;
+  const int utt = blockIdx.y;
+  const int T = utts.num_frames[utt];
+  const SampleT *w0 = wave + utts.wave_off[utt];
+  float *out0 = raw + utts.raw_base[utt] * kNumBins;
+
+  for (int t = blockIdx.x; t < T; t += gridDim.x) {
+    // ---- fbank.cc:74-100: the frame's 400 samples, 7 per lane (lane + 64 r)
+    const SampleT *w = w0 + (int64_t)t * kFrameShift;
+    float x[7];
+    bool exact = true;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      int i = lane + kWave * r;
+      x[r] = (i < kFrameLength) ? static_cast<float>(w[i]) : 0.0f;
+      // integer-valued samples of at most 16 bits: any summation order is exact
+      exact = exact && (fabsf(x[r]) <= 32768.0f) && (x[r] == truncf(x[r]));
+    }
+
+    // ---- fbank.cc:48-52: DC offset = sequential float sum / 400.
+    float sum;
+    if (__all(exact)) {
+      // 400 integers of magnitude <= 2^15: every partial sum is an integer below
+      // 2^24, so the tree sum equals the reference's sequential sum bit for bit.
+      float p = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + x[6]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
+      sum = p;
+    } else {
+      // general float input: keep the reference's order (one lane, 400 adds)
+#pragma unroll
+      for (int r = 0; r < 7; ++r) {
+        int i = lane + kWave * r;
+        if (i < kFrameLength) s_x[i] = x[r];
+      }
+      __syncthreads();
+      if (lane == 0) {
+        float s = 0;
+        for (int i = 0; i < kFrameLength; ++i) s += s_x[i];
+        s_sum = s;
+      }
+      __syncthreads();
+      sum = s_sum;
+      __syncthreads();
+    }
+    const float mean = sum / kFrameLength;
+
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      int i = lane + kWave * r;
+      x[r] -= mean;                                   // fbank.cc:53-55
+      if (i < kFrameLength) s_x[i] = x[r];
+    }
+    __syncthreads();
+
+    // ---- fbank.cc:58-68: pre-emphasis in double (0.97 is a double literal), one
+    // rounding to float, then the Hamming window.  De-interleave into re/im for
+    // the half-size complex FFT (srfft.cc:296-303); zero padding 400..511.
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      int i = lane + kWave * r;
+      float y = 0.0f;
+      if (r < 7 && i < kFrameLength) {
+        float prev = s_x[i > 0 ? i - 1 : 0];
+        y = static_cast<float>(static_cast<double>(x[r]) - 0.97 * static_cast<double>(prev));
+        y *= tab->window[i];
+      }
+      if (i & 1) s_im[i >> 1] = y; else s_re[i >> 1] = y;
+    }
+    __syncthreads();
+
+    // ---- srfft.cc:95-237 as passes over the block schedule
+    FftPass<8>(s_re, s_im, lane, tab);
+    FftPass<7>(s_re, s_im, lane, tab);
+    FftPass<6>(s_re, s_im, lane, tab);
+    FftPass<5>(s_re, s_im, lane, tab);
+    FftPass<4>(s_re, s_im, lane, tab);
+    FftPass<3>(s_re, s_im, lane, tab);
+    FftPass<2>(s_re, s_im, lane, tab);
+    {   // two-point blocks, srfft.cc:140-150
+      const int first = tab->pass_start[kNumPasses - 1];
+      const int nblk = tab->pass_start[kNumPasses] - first;
+      for (int b = lane; b < nblk; b += kWave) {
+        int off = tab->blk_off[first + b];
+        float tr = s_re[off] + s_re[off + 1];
+        s_re[off + 1] = s_re[off] - s_re[off + 1];
+        s_re[off] = tr;
+        float ti = s_im[off] + s_im[off + 1];
+        s_im[off + 1] = s_im[off] - s_im[off + 1];
+        s_im[off] = ti;
+      }
+    }
+    __syncthreads();
+
+    // ---- bit-reversed read (srfft.cc:239-265), real post-pass (srfft.cc:389-436)
+    // and power spectrum (fbank.cc:193-211) fused: bin k and its partner 256-k.
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int k = 1 + lane + kWave * r;            // 1..128
+      const int kd = kFftCplx - k;
+      const int jk = tab->bitrev[k], jd = tab->bitrev[kd];
+      const float bk_re = s_re[jk], bk_im = s_im[jk];
+      const float bd_re = s_re[jd], bd_im = s_im[jd];
+      const float kre = tab->post_re[k], kim = tab->post_im[k];
+      const float ck_re = 0.5f * (bk_re + bd_re);
+      const float ck_im = 0.5f * (bk_im - bd_im);
+      const float dk_re = 0.5f * (bk_im + bd_im);
+      const float dk_im = -0.5f * (bk_re - bd_re);
+      float a_re = ck_re, a_im = ck_im;
+      a_re += kre * dk_re - kim * dk_im;
+      a_im += kre * dk_im + kim * dk_re;
+      s_pow[k] = a_re * a_re + a_im * a_im;
+      if (kd != k) {
+        const float nk_re = -kre, ndk_im = -dk_im;
+        float o_re = ck_re, o_im = -ck_im;
+        o_re += nk_re * dk_re - kim * ndk_im;
+        o_im += nk_re * ndk_im + kim * dk_re;
+        s_pow[kd] = o_re * o_re + o_im * o_im;
+      }
+    }
+    if (lane == 0) {                                 // srfft.cc:444-447, fbank.cc:201-210
+      const float zeroth = s_re[0] + s_im[0], n2th = s_re[0] - s_im[0];
+      s_pow[0] = zeroth * zeroth;
+      s_pow[kFftCplx] = n2th * n2th;
+    }
+    __syncthreads();
+
+    // ---- fbank.cc:165-184 (sequential float dot per bin, vector.cc:252-262),
+    // floor FLT_EPSILON and log (fbank.cc:244-245)
+    if (lane < kNumBins) {
+      const int off = tab->mel_off[lane], len = tab->mel_len[lane];
+      float e = 0.0f;
+      for (int j = 0; j < len; ++j) e += tab->mel_w[j][lane] * s_pow[off + j];
+      if (e < 1.1920928955078125e-07f) e = 1.1920928955078125e-07f;
+      out0[(int64_t)t * kNumBins + lane] = static_cast<float>(log(static_cast<double>(e)));
+    }
+    __syncthreads();
+  }
+}
+
+// One lane per (utterance, feature); lanes walk the frames in order because the
+// running window sum is rounded to float every frame (cmvn.cc:66-70).
+__global__ __launch_bounds__(kWave) void CmvnKernel(const float *__restrict__ raw, UttLayout utts,
+                                                    const float *__restrict__ g, int left,
+                                                    int right, float *__restrict__ yt,
+                                                    int64_t ldy) {
+  const int d = threadIdx.x;
+  const int utt = blockIdx.x;
+  if (d >= kNumBins) return;
+  const int T = utts.num_frames[utt];
+  if (T <= 0) return;
+  const float *x0 = raw + utts.raw_base[utt] * kNumBins + d;
+  float *y0 = yt + (int64_t)d * ldy + utts.pad_base[utt];
+
+  const float gd = g[d];
+  const double global_count = g[kNumBins];
+  float s = 0.0f;      // cached window sum of this feature
+  float cnt = 0.0f;    // cached window count
+  float y = 0.0f;
+  constexpr int kStage = 8;   // frames fetched ahead of the serial recurrence
+  float xs[kStage], xps[kStage];
+  for (int t = 0; t < T; ++t) {
+    const int slot = t % kStage;
+    if (slot == 0) {
+      // the loads do not depend on the recurrence: issue a block of them together
+#pragma unroll
+      for (int u = 0; u < kStage; ++u) {
+        const int tt = t + u;
+        xs[u] = tt < T ? x0[(int64_t)tt * kNumBins] : 0.0f;
+        xps[u] = (tt < T && tt >= kCmvnWindow) ? x0[(int64_t)(tt - kCmvnWindow) * kNumBins] : 0.0f;
+      }
+    }
+    float x = xs[0], xp = xps[0];
+#pragma unroll
+    for (int u = 1; u < kStage; ++u)
+      if (slot == u) { x = xs[u]; xp = xps[u]; }
+    double acc = s, accn = cnt;                      // cmvn.cc:44-52
+    acc += x;
+    accn += 1.0;
+    if (t >= kCmvnWindow) {                          // cmvn.cc:58-64
+      acc += -1.0 * static_cast<double>(xp);
+      accn -= 1.0;
+    }
+    s = static_cast<float>(acc);                     // cmvn.cc:66-70
+    cnt = static_cast<float>(accn);
+
+    float st = s, ct = cnt;                          // cmvn.cc:73-92
+    const double count = ct;
+    if (count < kCmvnWindow) {
+      double from_global = kCmvnWindow - count;
+      if (from_global > kCmvnGlobalFrames) from_global = kCmvnGlobalFrames;
+      const float alpha = static_cast<float>(from_global / global_count);
+      st += alpha * gd;
+      ct += alpha * g[kNumBins];
+    }
+    const float scale = static_cast<float>(1 / static_cast<double>(ct));   // cmvn.cc:94-101
+    const float ns = -scale;
+    y = x;
+    y += ns * st;
+    y0[left + t] = y;
+    if (t == 0)
+      for (int p = 0; p < left; ++p) y0[p] = y;      // am.cc:73 clamp, done at write time
+  }
+  for (int p = 0; p < right; ++p) y0[left + T + p] = y;   // am.cc:74
+}
+
+__global__ void PadTransposeKernel(const float *__restrict__ feats, int T, int dim, int left,
+                                   int right, float *__restrict__ yt, int64_t ldy,
+                                   int64_t col0) {
+  const int total = T + left + right;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < (int64_t)total * dim;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int c = idx % total, d = idx / total;
+    int t = c - left;
+    t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+    yt[(int64_t)d * ldy + col0 + c] = feats[(int64_t)t * dim + d];
+  }
+}
+
+}  // namespace
+
+void LaunchFbank(const float *wave_f32, const int16_t *wave_i16, const UttLayout &utts,
+                 int num_utts, int max_frames, const FrontendTables *d_tables, float *raw,
+                 hipStream_t stream) {
+  if (num_utts <= 0 || max_frames <= 0) return;
+  int gx = 16384 / num_utts;
+  if (gx < 1) gx = 1;
+  if (gx > max_frames) gx = max_frames;
+  dim3 grid(gx, num_utts);
+  if (wave_i16)
+    hipLaunchKernelGGL(FbankKernel<int16_t>, grid, dim3(kWave), 0, stream, wave_i16, utts,
+                       d_tables, raw);
+  else
+    hipLaunchKernelGGL(FbankKernel<float>, grid, dim3(kWave), 0, stream, wave_f32, utts,
+                       d_tables, raw);
+}
+
+void LaunchCmvn(const float *raw, const UttLayout &utts, int num_utts, const float *d_global41,
+                int left, int right, float *yt, int64_t ldy, hipStream_t stream) {
+  if (num_utts <= 0) return;
+  hipLaunchKernelGGL(CmvnKernel, dim3(num_utts), dim3(kWave), 0, stream, raw, utts, d_global41,
+                     left, right, yt, ldy);
+}
+
+void LaunchPadTranspose(const float *feats, int T, int dim, int left, int right, float *yt,
+                        int64_t ldy, int64_t col0, hipStream_t stream) {
+  if (T <= 0) return;
+  int64_t n = (int64_t)(T + left + right) * dim;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(PadTransposeKernel, dim3(blocks), dim3(256), 0, stream, feats, T, dim, left,
+                     right, yt, ldy, col0);
+}
+
+}  // namespace pkmi

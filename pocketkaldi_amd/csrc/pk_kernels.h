@@ -1,0 +1,95 @@
+// pk_kernels.h -- host-callable launchers of the gfx950 kernels (internal).
+#ifndef PK_KERNELS_H_
+#define PK_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pk_tables.h"
+
+namespace pkmi {
+
+// ---------------------------------------------------------------- front-end
+
+// Per-utterance placement, all in device memory (arrays of num_utts entries).
+struct UttLayout {
+  const int64_t *wave_off;   // first PCM sample of the utterance in the wave buffer
+  const int32_t *num_frames; // T_u
+  const int64_t *raw_base;   // first row of the utterance in the raw fbank matrix [sum T][40]
+  const int64_t *pad_base;   // first column of the utterance in the padded feature-major CMVN matrix
+};
+
+// fbank.cc:267-292 for a batch: PCM -> raw log-mel features, frame-major [sum T][40].
+// wave is float PCM, or int16 PCM when wave_i16 != nullptr.
+void LaunchFbank(const float *wave_f32, const int16_t *wave_i16, const UttLayout &utts,
+                 int num_utts, int max_frames, const FrontendTables *d_tables, float *raw,
+                 hipStream_t stream);
+
+// cmvn.cc:103-115 for a batch: raw [sum T][40] -> feature-major, edge-padded
+// Yt[40][ldy]: utterance u occupies columns pad_base[u] .. pad_base[u]+T+left+right-1,
+// its frame t at column pad_base[u]+left+t, the first/last frame replicated into
+// the left/right pad (the clamp of am.cc:73-75 done once, at write time).
+void LaunchCmvn(const float *raw, const UttLayout &utts, int num_utts, const float *d_global41,
+                int left, int right, float *yt, int64_t ldy, hipStream_t stream);
+
+// Already-normalised features [T][dim] (frame-major) -> padded feature-major Yt.
+void LaunchPadTranspose(const float *feats, int T, int dim, int left, int right, float *yt,
+                        int64_t ldy, int64_t col0, hipStream_t stream);
+
+// ---------------------------------------------------------------- affine GEMM
+
+constexpr int kTile = 128;   // block tile edge (both output dimensions)
+constexpr int kBK = 16;      // k-step staged through LDS
+constexpr int kChunkK = 512; // gemm.h:50 KC: the reference's k-blocking (sets rounding points)
+
+// C[i][j] = sum_k P[k][i] * Q[k][j]  (+ bias, optional ReLU), fp32 MFMA.
+// P: [K][ldp] (i contiguous), Q: [K][ldq] (j contiguous); K multiple of kBK;
+// tiles_i x tiles_j tiles of 128x128 are computed, all buffers padded to that.
+// splice_dim > 0: Q is the feature-major CMVN matrix and row k of the operand is
+// Yt[k % splice_dim] shifted by k / splice_dim columns (am.cc:65-88 without
+// materialising the spliced matrix).
+struct GemmArgs {
+  const float *P;
+  int64_t ldp;
+  const float *Q;
+  int64_t ldq;
+  int K;
+  int splice_dim;
+  const float *bias;   // indexed by i (bias_on_j = 0) or j (bias_on_j = 1); padded
+  int bias_on_j;
+  int relu;
+  float *out;          // out[i * ldo + j]
+  int64_t ldo;
+  int tiles_i, tiles_j;
+};
+void LaunchGemm(const GemmArgs &a, hipStream_t stream);
+
+// ---------------------------------------------------------------- row-wise / elementwise
+
+// ReLU, nnet.cc:49-60 (x < 0 -> 0; -0.0 and NaN pass through)
+void LaunchRelu(float *x, int64_t n, hipStream_t stream);
+
+// Normalize, nnet.cc:62-75, for `frames` vectors of `dim` features; element
+// (frame f, feature d) lives at x[f * stride_f + d * stride_d].
+void LaunchNormalize(float *x, int frames, int dim, int64_t stride_f, int64_t stride_d,
+                     hipStream_t stream);
+
+// Feature-major [dim][ld_in] -> frame-major [frames][ld_out] and back.
+void LaunchTransposeToRows(const float *in, int64_t ld_in, int dim, int frames, float *out,
+                           int64_t ld_out, hipStream_t stream);
+void LaunchTransposeToCols(const float *in, int64_t ld_in, int frames, int dim, float *out,
+                           int64_t ld_out, hipStream_t stream);
+
+enum TailMode {
+  kTailSoftmaxProb = 0,    // SoftmaxLayer, nnet.cc:38-47: p = exp(x) / sum exp(x)
+  kTailSoftmaxLoglik = 1,  // + am.cc:106-112 + decodable.cc:15 fused:
+                           //   (max(log p, log 1e-20) - log_prior) * scale
+  kTailLoglik = 2          // no softmax layer: (log(max(x, 1e-20)) - log_prior) * scale
+};
+// in: [rows][ld_in] frame-major; out: [rows][ld_out]; n valid columns.
+void LaunchTail(int mode, const float *in, int64_t ld_in, int rows, int n, const float *log_prior,
+                float scale, float *out, int64_t ld_out, hipStream_t stream);
+
+}  // namespace pkmi
+
+#endif  // PK_KERNELS_H_

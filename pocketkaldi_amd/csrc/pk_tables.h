@@ -1,0 +1,60 @@
+// pk_tables.h -- constant tables of the front-end, built once on the host.
+//
+// The reference computes these at construction with float libm calls
+// (fbank.cc:103-163 mel triangles, fbank.cc:249-256 Hamming window,
+// srfft.cc:45-93 split-radix coefficient tables, srfft.cc:384-394 the iterated
+// real-FFT twiddle).  They do not depend on the audio, so we build them on the
+// host with the same arithmetic (host file compiled -O2 -ffp-contract=off, no
+// -march) and upload them; the kernels only do the per-frame arithmetic.
+#ifndef PK_TABLES_H_
+#define PK_TABLES_H_
+
+#include <stdint.h>
+
+namespace pkmi {
+
+constexpr int kSampleRate = 16000;
+constexpr int kFrameLength = 400;      // fbank.cc:15  (25 ms)
+constexpr int kFrameShift = 160;       // fbank.cc:14  (10 ms)
+constexpr int kFftSize = 512;          // fbank.cc:259 round-up to power of two
+constexpr int kFftCplx = 256;          // complex points of the half-size FFT
+constexpr int kLogCplx = 8;
+constexpr int kNumBins = 40;           // fbank.h:10
+constexpr int kCmvnWindow = 600;       // cmvn.h:10
+constexpr int kCmvnGlobalFrames = 200; // cmvn.h:11
+
+// Split-radix schedule: the sub-transforms of size 2^logm, logm = 8..1, in pass
+// order.  Pass p handles logm = 8 - p.  blk_off lists the block offsets of each
+// pass back to back; pass_start[p] indexes into it.
+constexpr int kNumPasses = 8;
+constexpr int kMaxBlocks = 171;        // 1+1+3+5+11+21+43+85 (+1 spare)
+
+// Twiddle tables: for logm = 4..8 six arrays of m/4 entries indexed by n
+// (entry 0 and entry m/8 unused).  Offsets into tw[] per logm.
+constexpr int kTwFloats = 6 * (4 + 8 + 16 + 32 + 64);
+
+constexpr int kMelMaxLen = 64;         // longest triangle (checked at build time)
+
+struct FrontendTables {
+  float window[kFrameLength];
+  // FFT
+  int32_t pass_start[kNumPasses + 1];
+  int32_t blk_off[kMaxBlocks + 1];
+  int32_t tw_off[kLogCplx + 1];        // tw_off[logm] -> start of the 6*(m/4) block
+  float tw[kTwFloats];
+  int32_t bitrev[kFftCplx];
+  float post_re[kFftCplx / 2 + 1];
+  float post_im[kFftCplx / 2 + 1];
+  // mel: weights stored [j][bin] so that the 40 lanes read consecutive words
+  int32_t mel_off[kNumBins];
+  int32_t mel_len[kNumBins];
+  int32_t mel_maxlen;
+  float mel_w[kMelMaxLen][kNumBins];
+};
+
+// Returns 0 on success.  Pure host code, no HIP.
+int BuildFrontendTables(FrontendTables *t);
+
+}  // namespace pkmi
+
+#endif  // PK_TABLES_H_

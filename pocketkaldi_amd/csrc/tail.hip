@@ -1,0 +1,220 @@
+// tail.hip -- the non-affine layers and the log-likelihood tail for gfx950:
+// ReLU (nnet.cc:49-60), Normalize (nnet.cc:62-75), Softmax (nnet.cc:38-47 ->
+// vector.cc:265-277), AcousticModel::Compute's floor/log/prior step
+// (am.cc:106-112) and the acoustic scale (decodable.cc:15), plus the two layout
+// changes between feature-major panels and frame-major rows.  All HBM-bound.
+#include <hip/hip_runtime.h>
+
+#include "pk_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace pkmi {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void ReluKernel(float *__restrict__ x, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t n4 = n / 4;
+  f32x4 *x4 = reinterpret_cast<f32x4 *>(x);
+  for (int64_t v = i; v < n4; v += stride) {
+    f32x4 t = x4[v];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t[c] = t[c] < 0.0f ? 0.0f : t[c];
+    x4[v] = t;
+  }
+  for (int64_t v = n4 * 4 + i; v < n; v += stride) x[v] = x[v] < 0.0f ? 0.0f : x[v];
+}
+
+// One lane per frame, features walked in ascending order: the float sum of
+// squares is the reference's sequential VecVec (vector.cc:252-262).
+__global__ void NormalizeKernel(float *__restrict__ x, int frames, int dim, int64_t stride_f,
+                                int64_t stride_d) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= frames) return;
+  float *row = x + (int64_t)f * stride_f;
+  float ss = 0.0f;
+  for (int d = 0; d < dim; ++d) {
+    const float v = row[(int64_t)d * stride_d];
+    ss += v * v;
+  }
+  const float D = static_cast<float>(dim);
+  const double squared_sum = ss;
+  const float scale = static_cast<float>(sqrt(D / squared_sum));     // nnet.cc:71-72
+  for (int d = 0; d < dim; ++d) row[(int64_t)d * stride_d] *= scale;
+}
+
+// 32 x 32 tile transpose through LDS (+1 padding), 256 threads.
+__global__ void TransposeKernel(const float *__restrict__ in, int64_t ld_in, int rows_in,
+                                int cols_in, float *__restrict__ out, int64_t ld_out) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int rr = r0 + r, cc = c0 + tx;
+    tile[r][tx] = (rr < rows_in && cc < cols_in) ? in[(int64_t)rr * ld_in + cc] : 0.0f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int orow = c0 + r, ocol = r0 + tx;                // out[c][r] = in[r][c]
+    if (orow < cols_in && ocol < rows_in) out[(int64_t)orow * ld_out + ocol] = tile[tx][r];
+  }
+}
+
+__device__ __forceinline__ float WaveMax(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float WaveSum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+constexpr int kTailThreads = 256;
+constexpr int kTailCache = 8;      // float4s per thread kept in registers (n <= 8192)
+
+// One workgroup per frame.  The row is read once (16-byte loads), kept in
+// registers, reduced with wavefront shuffles + a 4-entry LDS exchange, written once.
+template <int MODE>
+__global__ __launch_bounds__(kTailThreads) void TailKernel(const float *__restrict__ in,
+                                                           int64_t ld_in, int n,
+                                                           const float *__restrict__ log_prior,
+                                                           float scale, float *__restrict__ out,
+                                                           int64_t ld_out) {
+  __shared__ float red[kTailThreads / 64];
+  const int row = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float *x = in + (int64_t)row * ld_in;
+  float *y = out + (int64_t)row * ld_out;
+  const int n4 = (n + 3) / 4;                    // ld_in is padded, tail lanes masked below
+  const float kLogFloor = -46.051701859880914f;  // logf(1e-20f), am.cc:109-110
+
+  f32x4 v[kTailCache];
+  float m = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < kTailCache; ++c) {
+    const int q = tid + c * kTailThreads;
+    if (q < n4) {
+      v[c] = reinterpret_cast<const f32x4 *>(x)[q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (q * 4 + e < n) m = fmaxf(m, v[c][e]);
+    }
+  }
+
+  float lse = 0.0f, inv = 0.0f;
+  if (MODE != kTailLoglik) {
+    m = WaveMax(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kTailCache; ++c) {
+      const int q = tid + c * kTailThreads;
+      if (q < n4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (q * 4 + e < n) s += expf(v[c][e] - m);
+      }
+    }
+    s = WaveSum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    lse = m + logf(s);
+    inv = 1.0f / s;
+  }
+
+  const bool vec_out = ((ld_out & 3) == 0) && ((n & 3) == 0);
+#pragma unroll
+  for (int c = 0; c < kTailCache; ++c) {
+    const int q = tid + c * kTailThreads;
+    if (q < n4) {
+      f32x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = q * 4 + e;
+        float t = v[c][e];
+        if (MODE == kTailSoftmaxProb) {
+          t = expf(t - m) * inv;
+        } else {
+          if (MODE == kTailSoftmaxLoglik) t = t - lse;          // log softmax, stable form
+          else t = logf(t < 1.0e-20f ? 1.0e-20f : t);           // am.cc:109-110
+          if (t < kLogFloor) t = kLogFloor;                      // floor of am.cc:109 in the log domain
+          const float lp = col < n ? log_prior[col] : 0.0f;
+          t = (t + -1.0f * lp) * scale;                          // am.cc:111, decodable.cc:15
+        }
+        r[e] = t;
+      }
+      if (vec_out) {
+        reinterpret_cast<f32x4 *>(y)[q] = r;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (q * 4 + e < n) y[q * 4 + e] = r[e];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+void LaunchRelu(float *x, int64_t n, hipStream_t stream) {
+  if (n <= 0) return;
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(ReluKernel, dim3((int)blocks), dim3(256), 0, stream, x, n);
+}
+
+void LaunchNormalize(float *x, int frames, int dim, int64_t stride_f, int64_t stride_d,
+                     hipStream_t stream) {
+  if (frames <= 0) return;
+  hipLaunchKernelGGL(NormalizeKernel, dim3((frames + 63) / 64), dim3(64), 0, stream, x, frames,
+                     dim, stride_f, stride_d);
+}
+
+void LaunchTransposeToRows(const float *in, int64_t ld_in, int dim, int frames, float *out,
+                           int64_t ld_out, hipStream_t stream) {
+  if (dim <= 0 || frames <= 0) return;
+  dim3 grid((frames + 31) / 32, (dim + 31) / 32);
+  hipLaunchKernelGGL(TransposeKernel, grid, dim3(256), 0, stream, in, ld_in, dim, frames, out,
+                     ld_out);
+}
+
+void LaunchTransposeToCols(const float *in, int64_t ld_in, int frames, int dim, float *out,
+                           int64_t ld_out, hipStream_t stream) {
+  if (dim <= 0 || frames <= 0) return;
+  dim3 grid((dim + 31) / 32, (frames + 31) / 32);
+  hipLaunchKernelGGL(TransposeKernel, grid, dim3(256), 0, stream, in, ld_in, frames, dim, out,
+                     ld_out);
+}
+
+void LaunchTail(int mode, const float *in, int64_t ld_in, int rows, int n, const float *log_prior,
+                float scale, float *out, int64_t ld_out, hipStream_t stream) {
+  if (rows <= 0 || n <= 0) return;
+  dim3 grid(rows), block(kTailThreads);
+  switch (mode) {
+    case kTailSoftmaxProb:
+      hipLaunchKernelGGL(TailKernel<kTailSoftmaxProb>, grid, block, 0, stream, in, ld_in, n,
+                         log_prior, scale, out, ld_out);
+      break;
+    case kTailSoftmaxLoglik:
+      hipLaunchKernelGGL(TailKernel<kTailSoftmaxLoglik>, grid, block, 0, stream, in, ld_in, n,
+                         log_prior, scale, out, ld_out);
+      break;
+    default:
+      hipLaunchKernelGGL(TailKernel<kTailLoglik>, grid, block, 0, stream, in, ld_in, n, log_prior,
+                         scale, out, ld_out);
+      break;
+  }
+}
+
+}  // namespace pkmi

@@ -1,0 +1,87 @@
+"""Multi-GPU plumbing: one process per GPU, utterance-sharded, no data-path collective.
+
+The path shards by utterance (the only cross-frame state -- CMVN window, +-context
+splice -- lives inside one utterance), every rank holds a full weight replica, and
+the only exchange is ONE broadcast of the packed weight blob at load (RCCL over xGMI
+on GPUs; ``backend="nccl"`` is RCCL on ROCm).  These helpers are backend-agnostic
+so the same code is exercised with ``gloo`` on CPU in tests/test_dist_gloo.py.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torch.distributed.run environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def utterance_ids(rank, world, per_rank):
+    """Utterance u goes to rank u mod world; weak scaling: per_rank each."""
+    return [rank + world * i for i in range(per_rank)]
+
+
+def broadcast_blob(blob_u8, src=0):
+    """The one collective of the path: rank `src`'s weight blob to every rank, in place."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(blob_u8, src=src)
+    return blob_u8
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device="cpu"):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device="cpu"):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def all_ranks_agree(value, device="cpu"):
+    """True iff every rank holds the same float (used to verify the weight broadcast)."""
+    hi = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    lo = hi.clone()
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    return float(hi.item()) == float(lo.item())
+
+
+class DeviceBytes:
+    """A raw device allocation exposed through __cuda_array_interface__ so that
+    torch can alias it (zero-copy) for the broadcast."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1",
+                                         "data": (int(ptr), False), "version": 2}
+
+
+def alias_device_bytes(ptr, nbytes, device):
+    return torch.as_tensor(DeviceBytes(ptr, nbytes), device=device)
