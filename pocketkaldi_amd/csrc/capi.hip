@@ -709,7 +709,7 @@ struct pk_mi355_batch {
   float *d_global = nullptr;
   int max_utts = 0;
   int64_t max_samples = 0, max_frames = 0, max_cols = 0;
-  int64_t chunk = 8192;
+  int64_t chunk = 65536;   // frames per pass through the layer stack (PK_MI355_CHUNK overrides)
   // PCM
   float *d_wave = nullptr;          // owned float buffer
   int16_t *d_wave_i16 = nullptr;    // owned int16 buffer
