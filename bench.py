@@ -30,6 +30,17 @@ sys.path.insert(0, REPO)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
 
+def measured_traffic():
+    """HBM bytes per GEMM launch from the committed PMC passes (profiles/): bench.py cannot
+    run rocprofv3 around itself, so the number is the offline measurement of this same command."""
+    path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["gemm_avg_hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(model_name, seconds, num_utts):
     """Oracle port (oracle/pk_oracle*.c: scalar fbank/CMVN + blocked AVX2 SGEMM of the
     reference's class), ONE thread, on a bounded sample of the same workload."""
@@ -61,7 +72,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0, help="audio per utterance")
     ap.add_argument("--model", default="S", choices=["S", "W", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-utts", type=int, default=16)
+    ap.add_argument("--cpu-utts", type=int, default=64, help="utterances in the CPU-baseline sample (~15-20 s of CPU)")
     args = ap.parse_args()
 
     import torch
@@ -153,9 +164,18 @@ def main():
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "flop_per_frame": am.flops_per_frame(),
-                         "kernel_ms_per_step": gemm_ms, "traffic": None},
+                         "kernel_ms_per_step": gemm_ms,
+                         "algorithmic_bytes_per_launch": None, "traffic": None},
             "stage_ms_per_step": {k: tm[k][0] for k in pk.KINDS},
         }
+        if args.model == "S" and args.batch == 256 and gemm_launches:
+            out["roofline"]["traffic"] = measured_traffic()
+            # operands read once + output written once, averaged over the launches of a step
+            # (layer 1 reads the 40-dim features, the splice is a view)
+            lay = [(40, 440, 1024)] + [(1024, 1024, 1024)] * 3 + [(1024, 1024, 3000)]
+            rows = frames_per_step + 10 * args.batch
+            out["roofline"]["algorithmic_bytes_per_launch"] = (
+                sum(4.0 * (rows * kin + k * n + rows * n) for kin, k, n in lay) / gemm_launches)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, args.seconds, args.cpu_utts)
         print(json.dumps(out), flush=True)

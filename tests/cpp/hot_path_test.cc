@@ -1,0 +1,119 @@
+// hot_path_test.cc -- the reference's own test programs for this path (test/fbank_test.cc,
+// test/cmvn_test.cc, test/nnet_test.cc), re-expressed against include/pocketkaldi_amd.hpp:
+// a C++ caller written the way the reference's callers are, linked to libpk_mi355.so.
+// Built and run by tests/test_gpu_cpp.py (needs a GPU); `--link-only` exits before any compute.
+#include <assert.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "pocketkaldi_amd.hpp"
+
+using pocketkaldi::AcousticModel;
+using pocketkaldi::CMVN;
+using pocketkaldi::Fbank;
+
+#define CHECK(cond) do { if (!(cond)) { fprintf(stderr, "CHECK failed: %s (%s:%d) last error: %s\n", #cond, __FILE__, __LINE__, pk_mi355_last_error()); exit(1); } } while (0)
+
+static std::vector<float> ReadArray(const std::string &path) {
+  std::ifstream is(path);
+  std::vector<float> v;
+  double x;
+  while (is >> x) v.push_back(static_cast<float>(x));
+  return v;
+}
+
+// 44-byte-header 16-bit PCM, as pk_16kpcm_read accepts (src/pcm_reader.cc:45-220)
+static std::vector<float> ReadWav16(const std::string &path) {
+  std::ifstream is(path, std::ios::binary);
+  std::vector<char> bytes((std::istreambuf_iterator<char>(is)), std::istreambuf_iterator<char>());
+  CHECK(bytes.size() > 44 && memcmp(bytes.data(), "RIFF", 4) == 0);
+  std::vector<float> s((bytes.size() - 44) / 2);
+  for (size_t i = 0; i < s.size(); ++i) {
+    int16_t v;
+    memcpy(&v, &bytes[44 + 2 * i], 2);
+    s[i] = v;
+  }
+  return s;
+}
+
+static std::vector<float> ReadVec0(const std::string &path) {
+  std::ifstream is(path, std::ios::binary);
+  char head[12];
+  is.read(head, 12);
+  CHECK(memcmp(head, "VEC0", 4) == 0);
+  int32_t n;
+  memcpy(&n, head + 8, 4);
+  std::vector<float> v(n);
+  is.read(reinterpret_cast<char *>(v.data()), 4 * n);
+  return v;
+}
+
+static void TestFbankAndCmvn(const std::string &dir) {      // test/fbank_test.cc:15-56, test/cmvn_test.cc:33-82
+  std::vector<float> pcm = ReadWav16(dir + "en-us-hello.wav");
+  CHECK(pcm.size() == 7802);
+  pk_vector_t pcm_data = {static_cast<int>(pcm.size()), pcm.data()};
+  Fbank fbank;
+  pk_matrix_t fbank_feat = {0, 0, nullptr};
+  fbank.Compute(&pcm_data, &fbank_feat);
+  CHECK(fbank.last_status().ok());
+  CHECK(fbank_feat.ncol == 47 && fbank_feat.nrow == 40);
+  std::vector<float> corr = ReadArray(dir + "fbankmat_en-us-hello.wav.txt");
+  CHECK(corr.size() == 47u * 40u);
+  for (size_t i = 0; i < corr.size(); ++i) CHECK(fabs(fbank_feat.data[i] - corr[i]) < 3e-5);
+
+  std::vector<float> stats = ReadVec0(dir + "cmvn_stats.bin");
+  CHECK(stats.size() == 41);
+  pk_vector_t global_stats = {41, stats.data()};
+  CMVN cmvn(&global_stats, &fbank_feat);
+  std::vector<float> corr2 = ReadArray(dir + "fbankcmvnmat_en-us-hello.wav.txt");
+  pk_vector_t feats = {0, nullptr};
+  for (int i = 0; i < fbank_feat.ncol; ++i) {
+    cmvn.GetFrame(i, &feats);
+    CHECK(cmvn.last_status().ok() && feats.dim == 40);
+    for (int d = 0; d < feats.dim; ++d) CHECK(fabs(feats.data[d] - corr2[i * feats.dim + d]) < 3e-5);
+  }
+  free(feats.data);
+  free(fbank_feat.data);
+}
+
+static void TestLinearLayerThroughDecodable() {              // test/nnet_test.cc:23-55 numbers
+  float W[] = {0.1f, 0.8f, 0.9f, 0.4f, 0.2f, 0.7f, 0.2f, 0.1f, 0.1f, 0.4f, 0.3f, 0.2f};
+  float b[] = {0.1f, -0.1f, 0.2f, -0.2f};
+  AcousticModel am;
+  CHECK(am.AddLinear(3, 4, W, b).ok());
+  std::vector<float> prior(4, 1.0f);          // log prior = 0
+  std::vector<int32_t> tid2pdf = {0, 3, 2, 1, 0};
+  CHECK(am.Finalize(prior, 0, 0, tid2pdf).ok());
+  CHECK(am.num_pdfs() == 4 && am.TransitionIdToPdfId(1) == 3);
+  float x[] = {0.3f, -0.1f, 0.9f};
+  pk_matrix_t feats = {1, 3, x};
+  pk_decodable_t d;
+  pk_decodable_init(&d, am.handle(), 1.0f, &feats);
+  CHECK(d.log_prob.ncol == 1 && d.log_prob.nrow == 4);
+  const float y[] = {0.86f, 0.63f, 0.34f, 0.07f};           // expected layer outputs
+  for (int i = 0; i < 4; ++i) CHECK(fabs(d.log_prob.data[i] - logf(y[i])) < 1e-5);
+  CHECK(!pk_decodable_islastframe(&d, -1));                 // first poll of Decoder::Decode
+  CHECK(pk_decodable_islastframe(&d, 0));
+  CHECK(pk_decodable_loglikelihood(&d, 0, 1) == d.log_prob.data[3]);
+  pk_decodable_destroy(&d);
+  CHECK(d.log_prob.data == nullptr);
+}
+
+int main(int argc, char **argv) {
+  if (argc > 1 && strcmp(argv[1], "--link-only") == 0) {
+    printf("%s\n", pk_mi355_version());
+    return 0;
+  }
+  std::string dir = argc > 1 ? argv[1] : "tests/golden/";
+  if (dir.back() != '/') dir += '/';
+  TestFbankAndCmvn(dir);
+  TestLinearLayerThroughDecodable();
+  printf("hot_path_test ok\n");
+  return 0;
+}

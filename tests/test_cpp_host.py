@@ -1,0 +1,31 @@
+"""The C++ host mirror (include/pocketkaldi_amd.hpp): a caller shaped like the reference's own
+test programs compiles against the headers and links to libpk_mi355.so (CPU), and passes on a GPU."""
+import os
+import subprocess
+
+import pytest
+
+import pocketkaldi_amd as pk
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(REPO, "tests", "cpp", "hot_path_test.cc")
+BIN = os.path.join(REPO, "tests", "cpp", "hot_path_test.bin")
+
+
+def build_binary():
+    pk.lib()
+    libdir = os.path.dirname(pk.lib_path())
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-I", os.path.join(REPO, "include"), SRC, "-o", BIN,
+                           "-L", libdir, "-l:libpk_mi355.so", "-Wl,-rpath," + libdir])
+    return BIN
+
+
+def test_cpp_caller_compiles_and_links():
+    out = subprocess.check_output([build_binary(), "--link-only"], text=True)
+    assert "pk_mi355" in out
+
+
+@pytest.mark.gpu
+def test_cpp_caller_runs_reference_style_tests():
+    out = subprocess.check_output([build_binary(), os.path.join(REPO, "tests", "golden")], text=True)
+    assert "hot_path_test ok" in out
