@@ -99,7 +99,8 @@ def main():
                   for l in layers]
         prior = np.full_like(prior, 1.0)
     am = pk.AcousticModel(layers, prior, L, R)
-    if world > 1:
+    import torch.distributed as tdist
+    if world > 1 or tdist.is_initialized():
         ptr, nbytes = am.blob()
         blob = pkdist.alias_device_bytes(ptr, nbytes, dev)
         pkdist.broadcast_blob(blob, src=0)          # the one RCCL collective of the path
@@ -115,7 +116,7 @@ def main():
     frames_per_step = bs.total_frames()
 
     # ---- broadcast check: every rank scores utterance 0 with its replica
-    if world > 1:
+    if world > 1 or tdist.is_initialized():
         chk = pk.BatchScorer(am, synth.global_cmvn_stats(), 1, 16000)
         chk.set_waves([synth.utterance(0, 1.0)])
         chk.score(0.1)

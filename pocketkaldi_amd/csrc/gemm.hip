@@ -19,8 +19,9 @@
 // second register set: results are bit-identical to the reference's SGEMM.
 //
 // Tile: 128 x 128 per 256-thread workgroup (4 waves as 2 x 2, 64 x 64 per wave =
-// 2 x 2 MFMA tiles), BK = 16, a ring of three LDS slabs (48 KiB) with two slabs of
-// DMA in flight, one raw s_barrier per slab.
+// 2 x 2 MFMA tiles with interleaved rows), BK = 16, a ring of three LDS slabs
+// (48 KiB) with two slabs of DMA in flight, one raw s_barrier per slab, three
+// workgroups per CU.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -33,11 +34,12 @@ namespace pkmi {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 256;
 constexpr int kSlab = kBK * kTile;          // floats per operand per slab
 constexpr int kRing = 3;                    // LDS slabs in the ring
-constexpr int kDmaPerWave = 4;              // x4 DMA instructions one wave issues per slab
+constexpr int kDmaPerWave = 4;              // x4 DMA pieces one wave issues per slab
 
 typedef const __attribute__((address_space(1))) void *GlobalPtr;
 typedef __attribute__((address_space(3))) void *LdsPtr;
@@ -47,46 +49,37 @@ typedef __attribute__((address_space(3))) void *LdsPtr;
 // wave-instruction moves 64 lanes x 16 B = two 512-byte k-rows; wave w owns rows
 // 4w..4w+3 of P and of Q.  The LDS destination is wave-uniform base + lane * 16
 // (hardware), the global source is per lane.
-template <bool SPLICE, bool SPLICE_X4>
+template <bool SPLICE>
 __device__ __forceinline__ void IssuePiece(const GemmArgs &a, const float *__restrict__ pg,
                                            const float *__restrict__ qg, int k0, int wave, int lane,
-                                           float *smem, int slot, int piece) {
+                                           uint32_t lane_off_p, uint32_t lane_off_q, float *smem,
+                                           int slot, int piece) {
   float *ps = smem + (slot * 2 + 0) * kSlab;
   float *qs = smem + (slot * 2 + 1) * kSlab;
-  const int lrow = lane >> 5, lcol = (lane & 31) * 4;
+  // Plain panels: wave-uniform 64-bit row base (scalar registers) + a loop-invariant
+  // 32-bit per-lane byte offset, so a piece costs scalar address math only.
   if (piece < 2) {                                    // P rows, x4
     const int row = wave * 4 + piece * 2;             // wave-uniform
-    const int k = k0 + row + lrow;
-    __builtin_amdgcn_global_load_lds((GlobalPtr)(pg + (int64_t)k * a.ldp + lcol),
-                                     (LdsPtr)(ps + row * kTile), 16, 0, 0);
-  } else if (!SPLICE || SPLICE_X4) {                  // Q rows, x4
+    const char *base = reinterpret_cast<const char *>(pg + (int64_t)(k0 + row) * a.ldp);
+    __builtin_amdgcn_global_load_lds((GlobalPtr)(base + lane_off_p), (LdsPtr)(ps + row * kTile), 16, 0, 0);
+  } else if (!SPLICE) {                               // Q rows, x4
     const int row = wave * 4 + (piece - 2) * 2;
-    const int k = k0 + row + lrow;
-    if (!SPLICE) {
-      __builtin_amdgcn_global_load_lds((GlobalPtr)(qg + (int64_t)k * a.ldq + lcol),
-                                       (LdsPtr)(qs + row * kTile), 16, 0, 0);
-    } else {
-      // am.cc:65-88 without materialising: operand row k is feature (k % D) of the
-      // padded feature-major matrix, shifted by (k / D) frames (4-byte aligned source).
-      const int c = k / a.splice_dim, d = k - c * a.splice_dim;
-      __builtin_amdgcn_global_load_lds((GlobalPtr)(qg + (int64_t)d * a.ldq + c + lcol),
-                                       (LdsPtr)(qs + row * kTile), 16, 0, 0);
-    }
-  } else {                                            // spliced Q rows, dword DMA: 64 frames of one k-row
-    const int row = wave * 4 + (piece - 2) / 2;
-    const int k = k0 + row;
+    const char *base = reinterpret_cast<const char *>(qg + (int64_t)(k0 + row) * a.ldq);
+    __builtin_amdgcn_global_load_lds((GlobalPtr)(base + lane_off_q), (LdsPtr)(qs + row * kTile), 16, 0, 0);
+  } else {
+    // am.cc:65-88 without materialising: operand row k is feature (k % D) of the
+    // padded feature-major matrix, shifted by (k / D) frames.  The source is only
+    // 4-byte aligned; x4 LDS-DMA takes that on gfx950 (bit-exact in the parity tests).
+    const int row = wave * 4 + (piece - 2) * 2;
+    const int k = k0 + row + (lane >> 5);
     const int c = k / a.splice_dim, d = k - c * a.splice_dim;
-    const int off = ((piece - 2) & 1) * 64;
-    __builtin_amdgcn_global_load_lds((GlobalPtr)(qg + (int64_t)d * a.ldq + c + off + lane),
-                                     (LdsPtr)(qs + row * kTile + off), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((GlobalPtr)(qg + (int64_t)d * a.ldq + c + (lane & 31) * 4),
+                                     (LdsPtr)(qs + row * kTile), 16, 0, 0);
   }
 }
 
-template <bool SPLICE, bool SPLICE_X4>
-constexpr int DmaCount() { return (SPLICE && !SPLICE_X4) ? 2 + 8 : kDmaPerWave; }   // pieces per wave per slab
-
-template <bool SPLICE, bool SPLICE_X4, bool MULTICHUNK, bool BIAS_J, bool RELU>
-__global__ __launch_bounds__(kThreads, 2) void GemmKernel(GemmArgs a) {
+template <bool SPLICE, bool MULTICHUNK, bool BIAS_J, bool RELU>
+__global__ __launch_bounds__(kThreads, 3) void GemmKernel(GemmArgs a) {
   // ALL LDS in one array (a second __shared__ object makes hipcc drain the DMA
   // queue before every LDS read)
   __shared__ __attribute__((aligned(16))) float smem[kRing * 2 * kSlab];
@@ -112,6 +105,9 @@ __global__ __launch_bounds__(kThreads, 2) void GemmKernel(GemmArgs a) {
   const int half = lane >> 5, l31 = lane & 31;
   const float *pg = a.P + i0;
   const float *qg = a.Q + j0;
+  // byte offset of this lane inside a two-row DMA piece (rows k, k+1; 16 bytes per lane)
+  const uint32_t lane_off_p = (uint32_t)(((lane >> 5) * a.ldp + (lane & 31) * 4) * sizeof(float));
+  const uint32_t lane_off_q = (uint32_t)(((lane >> 5) * a.ldq + (lane & 31) * 4) * sizeof(float));
 
   f32x16 acc[2][2], done[2][2];
 #pragma unroll
@@ -123,22 +119,26 @@ __global__ __launch_bounds__(kThreads, 2) void GemmKernel(GemmArgs a) {
     }
 
   const int nkt = a.K / kBK;
-  constexpr int kDma = DmaCount<SPLICE, SPLICE_X4>();
+  constexpr int kDma = kDmaPerWave;
 
   auto issue_slab = [&](int kt, int slot) {
 #pragma unroll
     for (int p = 0; p < kDma; ++p)
-      IssuePiece<SPLICE, SPLICE_X4>(a, pg, qg, kt * kBK, wave, lane, smem, slot, p);
+      IssuePiece<SPLICE>(a, pg, qg, kt * kBK, wave, lane, lane_off_p, lane_off_q, smem, slot, p);
   };
-  // fragments of k-steps [first, first+4) of the slab in `slot`
+  // fragments of k-steps [first, first+4) of the slab in `slot`.  Sub-tile a of a wave
+  // takes the rows I0 + 2 i' + a (i' = lane & 31), so the two P values (and the two Q
+  // values) a lane needs are adjacent: one 8-byte LDS read each, conflict-free, all
+  // k-steps reachable through the instruction's immediate offset.
   auto read_frags = [&](int slot, int first, float (&pf)[kBK / 4][2], float (&qf)[kBK / 4][2]) {
-    const float *ps = smem + (slot * 2 + 0) * kSlab + wi * 64 + l31 + half * kTile;
-    const float *qs = smem + (slot * 2 + 1) * kSlab + wj * 64 + l31 + half * kTile;
+    const f32x2 *ps = reinterpret_cast<const f32x2 *>(smem + (slot * 2 + 0) * kSlab + wi * 64 + 2 * l31 + half * kTile);
+    const f32x2 *qs = reinterpret_cast<const f32x2 *>(smem + (slot * 2 + 1) * kSlab + wj * 64 + 2 * l31 + half * kTile);
 #pragma unroll
     for (int ks = 0; ks < kBK / 4; ++ks) {
-      const int kk = 2 * (first + ks) * kTile;
-      pf[ks][0] = ps[kk]; pf[ks][1] = ps[kk + 32];
-      qf[ks][0] = qs[kk]; qf[ks][1] = qs[kk + 32];
+      const int kk = (first + ks) * kTile;            // in float2 units: 2 k-rows = 2 * 128 floats
+      const f32x2 p = ps[kk], q = qs[kk];
+      pf[ks][0] = p[0]; pf[ks][1] = p[1];
+      qf[ks][0] = q[0]; qf[ks][1] = q[1];
     }
   };
   auto mfma4 = [&](const float (&pf)[kBK / 4][2], const float (&qf)[kBK / 4][2], int ks) {
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kThreads, 2) void GemmKernel(GemmArgs a) {
       if (dma) {
 #pragma unroll
         for (int p = ks * kDma / 4; p < (ks + 1) * kDma / 4; ++p)
-          IssuePiece<SPLICE, SPLICE_X4>(a, pg, qg, (kt + 2) * kBK, wave, lane, smem, slot2, p);
+          IssuePiece<SPLICE>(a, pg, qg, (kt + 2) * kBK, wave, lane, lane_off_p, lane_off_q, smem, slot2, p);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -218,47 +218,51 @@ __global__ __launch_bounds__(kThreads, 2) void GemmKernel(GemmArgs a) {
     slot = slot1;
   }
 
-  // ---- epilogue: D[i][j], column j on the lane, rows i in the 16 registers
-  // (i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)); 128-byte row segments per store.
-  // The bias values are fetched in one batch (a per-element runtime select makes
-  // hipcc branch around every load and wait for each one).
-  float bj[2] = {0.0f, 0.0f};
+  // ---- epilogue.  Accumulator acc[x][y], register r, lane (l31, half) holds
+  // D[I0 + 2 i' + x][J0 + 2 l31 + y] with i' = (r & 3) + 8 (r >> 2) + 4 half: the y = 0/1
+  // pair is adjacent in memory, so a row is written as 32 lanes x 8 bytes = 256 contiguous
+  // bytes per store.  The bias values are fetched in one batch (a per-element runtime
+  // select makes hipcc branch around every load and wait for each one).
+  const int I0 = i0 + wi * 64, J0 = j0 + wj * 64;
+  f32x2 bj = {0.0f, 0.0f};
   float bi[2][16];
   if (BIAS_J) {
-#pragma unroll
-    for (int y = 0; y < 2; ++y) bj[y] = a.bias[j0 + wj * 64 + y * 32 + l31];
+    bj = *reinterpret_cast<const f32x2 *>(a.bias + J0 + 2 * l31);
   } else {
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        bi[x][r] = a.bias[i0 + wi * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+    for (int r = 0; r < 16; ++r) {
+      const f32x2 t = *reinterpret_cast<const f32x2 *>(a.bias + I0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * half));
+      bi[0][r] = t[0];
+      bi[1][r] = t[1];
+    }
   }
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+  for (int x = 0; x < 2; ++x) {
+    float *obase = a.out + (int64_t)(I0 + 8 * half + x) * a.ldo + J0 + 2 * l31;
 #pragma unroll
-    for (int y = 0; y < 2; ++y) {
-      const int jj = j0 + wj * 64 + y * 32 + l31;
-      float *orow = a.out + (int64_t)(i0 + wi * 64 + x * 32 + 4 * half) * a.ldo + jj;
+    for (int r = 0; r < 16; ++r) {
+      f32x2 v;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[x][y][r];
-        if (MULTICHUNK) v = done[x][y][r] + v;
-        v += BIAS_J ? bj[y] : bi[x][r];                // nnet.cc:32-35
-        if (RELU) v = v < 0.0f ? 0.0f : v;             // nnet.cc:56-58
-        orow[(int64_t)((r & 3) + 8 * (r >> 2)) * a.ldo] = v;
+      for (int y = 0; y < 2; ++y) {
+        float t = acc[x][y][r];
+        if (MULTICHUNK) t = done[x][y][r] + t;
+        t += BIAS_J ? bj[y] : bi[x][r];                // nnet.cc:32-35
+        if (RELU) t = t < 0.0f ? 0.0f : t;             // nnet.cc:56-58
+        v[y] = t;
       }
+      *reinterpret_cast<f32x2 *>(obase + (int64_t)(2 * ((r & 3) + 8 * (r >> 2))) * a.ldo) = v;
     }
+  }
 }
 
-template <bool SPLICE, bool SPLICE_X4, bool MULTICHUNK>
+template <bool SPLICE, bool MULTICHUNK>
 void LaunchVariant(const GemmArgs &a, dim3 grid, dim3 block, hipStream_t stream) {
   if (a.bias_on_j) {
-    if (a.relu) hipLaunchKernelGGL((GemmKernel<SPLICE, SPLICE_X4, MULTICHUNK, true, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((GemmKernel<SPLICE, SPLICE_X4, MULTICHUNK, true, false>), grid, block, 0, stream, a);
+    if (a.relu) hipLaunchKernelGGL((GemmKernel<SPLICE, MULTICHUNK, true, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((GemmKernel<SPLICE, MULTICHUNK, true, false>), grid, block, 0, stream, a);
   } else {
-    if (a.relu) hipLaunchKernelGGL((GemmKernel<SPLICE, SPLICE_X4, MULTICHUNK, false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((GemmKernel<SPLICE, SPLICE_X4, MULTICHUNK, false, false>), grid, block, 0, stream, a);
+    if (a.relu) hipLaunchKernelGGL((GemmKernel<SPLICE, MULTICHUNK, false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((GemmKernel<SPLICE, MULTICHUNK, false, false>), grid, block, 0, stream, a);
   }
 }
 
@@ -269,18 +273,12 @@ void LaunchGemm(const GemmArgs &a, hipStream_t stream) {
   const int nblk = super_i * super_j * 64;
   const bool multi = a.K > kChunkK;
   dim3 grid(nblk), block(kThreads);
-  static const bool splice_x4 = getenv("PK_MI355_SPLICE_DWORD") == nullptr;
   if (a.splice_dim > 0) {
-    if (splice_x4) {
-      if (multi) LaunchVariant<true, true, true>(a, grid, block, stream);
-      else LaunchVariant<true, true, false>(a, grid, block, stream);
-    } else {
-      if (multi) LaunchVariant<true, false, true>(a, grid, block, stream);
-      else LaunchVariant<true, false, false>(a, grid, block, stream);
-    }
+    if (multi) LaunchVariant<true, true>(a, grid, block, stream);
+    else LaunchVariant<true, false>(a, grid, block, stream);
   } else {
-    if (multi) LaunchVariant<false, false, true>(a, grid, block, stream);
-    else LaunchVariant<false, false, false>(a, grid, block, stream);
+    if (multi) LaunchVariant<false, true>(a, grid, block, stream);
+    else LaunchVariant<false, false>(a, grid, block, stream);
   }
 }
 

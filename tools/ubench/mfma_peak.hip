@@ -5,9 +5,11 @@
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int MODE>   // 0: registers only; 1: LDS reads per k-step; 2: LDS reads + barrier per 32 MFMA
-__global__ __launch_bounds__(256) void K(float *out, int iters) {
-  __shared__ float lds[2 * 16 * 128];
+typedef const __attribute__((address_space(1))) void *GlobalPtr;
+typedef __attribute__((address_space(3))) void *LdsPtr;
+template <int MODE>   // 0: registers only; 1: LDS reads per k-step; 2: + barrier per 32 MFMA; 3: + 4 LDS-DMA pieces per 32 MFMA
+__global__ __launch_bounds__(256) void K(float *out, int iters, const float *src) {
+  __shared__ float lds[3 * 2 * 16 * 128];
   const int lane = threadIdx.x & 63;
   for (int i = threadIdx.x; i < 2 * 16 * 128; i += 256) lds[i] = 1.0f + i * 1e-6f;
   __syncthreads();
@@ -32,6 +34,15 @@ __global__ __launch_bounds__(256) void K(float *out, int iters) {
       a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, a2, 0, 0, 0);
       a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, a3, 0, 0, 0);
     }
+    if (MODE == 3) {
+      const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+      const float *g = src + ((size_t)blockIdx.x * 64 + (it & 1023)) * 4096 + wave * 1024 + lane * 4;
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        __builtin_amdgcn_global_load_lds((GlobalPtr)(g + p * 256), (LdsPtr)(lds + 4096 + ((it % 2) * 4096) + wave * 1024 + p * 256), 16, 0, 0);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     if (MODE == 2) __syncthreads();
   }
   float s = 0;
@@ -39,14 +50,15 @@ __global__ __launch_bounds__(256) void K(float *out, int iters) {
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+static float *src;
 template <int MODE>
 void run(int blocks_per_cu, int iters, float *d) {
   int blocks = 256 * blocks_per_cu;
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  K<MODE><<<blocks, 256>>>(d, 10);
+  K<MODE><<<blocks, 256>>>(d, 10, src);
   hipDeviceSynchronize();
   hipEventRecord(a);
-  K<MODE><<<blocks, 256>>>(d, iters);
+  K<MODE><<<blocks, 256>>>(d, iters, src);
   hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b);
   double flops = (double)blocks * 4 * iters * 32 * 4096.0;
@@ -55,6 +67,7 @@ void run(int blocks_per_cu, int iters, float *d) {
 
 int main() {
   float *d; hipMalloc(&d, 256 * 8 * 256 * 4);
-  for (int bpc = 1; bpc <= 4; ++bpc) { run<0>(bpc, 4000, d); run<1>(bpc, 4000, d); run<2>(bpc, 4000, d); }
+  hipMalloc(&src, (size_t)1024 * 64 * 4096 * 4 + (1 << 24)); hipMemset(src, 0, (size_t)1024 * 64 * 4096 * 4);
+  for (int bpc = 1; bpc <= 3; ++bpc) { run<0>(bpc, 4000, d); run<1>(bpc, 4000, d); run<2>(bpc, 4000, d); run<3>(bpc, 4000, d); }
   return 0;
 }
