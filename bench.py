@@ -169,6 +169,16 @@ def main():
                          "algorithmic_bytes_per_launch": None, "traffic": None},
             "stage_ms_per_step": {k: tm[k][0] for k in pk.KINDS},
         }
+        # the HBM-bound stages against the 8 TB/s peak (algorithmic
+        # bytes per frame = 800 fbank, 320 CMVN, 2 * 4 * num_pdfs log-softmax tail)
+        hbm_peak = 8000.0
+        per_frame = {"fbank": 800.0, "cmvn": 320.0, "tail": 8.0 * pdfs}
+        out["stage_roofline"] = {}
+        for k, bpf in per_frame.items():
+            ms = tm[k][0]
+            gbs = bpf * frames_per_step / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            out["stage_roofline"][k] = {"bound": "hbm", "bytes_per_frame": bpf, "achieved": gbs,
+                                        "peak": hbm_peak, "unit": "GB/s", "frac": gbs / hbm_peak}
         if args.model == "S" and args.batch == 256 and gemm_launches:
             out["roofline"]["traffic"] = measured_traffic()
             # operands read once + output written once, averaged over the launches of a step

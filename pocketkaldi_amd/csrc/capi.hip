@@ -707,6 +707,7 @@ struct pk_mi355_batch {
   Timer timer;
   FrontendTables *d_tables = nullptr;
   float *d_global = nullptr;
+  CmvnTables *d_cmvn_tab = nullptr;
   int max_utts = 0;
   int64_t max_samples = 0, max_frames = 0, max_cols = 0;
   int64_t chunk = 65536;   // frames per pass through the layer stack (PK_MI355_CHUNK overrides)
@@ -809,6 +810,10 @@ pk_mi355_batch_t *pk_mi355_batch_create(pk_mi355_am_t *am, const float *global_s
   if (ok) chk(hipMemcpy(b->d_tables, &host, sizeof(FrontendTables), hipMemcpyHostToDevice));
   chk(hipMalloc(&b->d_global, sizeof(float) * (kNumBins + 1)));
   if (ok) chk(hipMemcpy(b->d_global, global_stats41, sizeof(float) * (kNumBins + 1), hipMemcpyHostToDevice));
+  CmvnTables ctab;
+  BuildCmvnTables(global_stats41[kNumBins], &ctab);
+  chk(hipMalloc(&b->d_cmvn_tab, sizeof(CmvnTables)));
+  if (ok) chk(hipMemcpy(b->d_cmvn_tab, &ctab, sizeof(CmvnTables), hipMemcpyHostToDevice));
   chk(hipMalloc(&b->d_wave_off, sizeof(int64_t) * max_utts));
   chk(hipMalloc(&b->d_raw_base, sizeof(int64_t) * max_utts));
   chk(hipMalloc(&b->d_pad_base, sizeof(int64_t) * max_utts));
@@ -827,7 +832,7 @@ void pk_mi355_batch_destroy(pk_mi355_batch_t *b) {
   hipSetDevice(b->device);
   if (b->stream) hipStreamSynchronize(b->stream);
   FreeExec(&b->exec);
-  hipFree(b->d_tables); hipFree(b->d_global);
+  hipFree(b->d_tables); hipFree(b->d_global); hipFree(b->d_cmvn_tab);
   hipFree(b->d_wave); hipFree(b->d_wave_i16);
   hipFree(b->d_wave_off); hipFree(b->d_raw_base); hipFree(b->d_pad_base); hipFree(b->d_T);
   hipFree(b->d_raw); hipFree(b->d_yt); hipFree(b->d_ll);
@@ -895,7 +900,7 @@ int pk_mi355_batch_score(pk_mi355_batch_t *b, float prob_scale, int sync) {
   }
   {
     Scoped t(tm, PK_MI355_K_CMVN, b->stream);
-    LaunchCmvn(b->d_raw, lay, b->num_utts, b->d_global, am->left, am->right, b->d_yt, b->ldy, b->stream);
+    LaunchCmvn(b->d_raw, lay, b->num_utts, b->d_global, b->d_cmvn_tab, am->left, am->right, b->d_yt, b->ldy, b->stream);
   }
   // Rows of the spliced operand = padded columns; row r of utterance u (r in
   // [pad_base, pad_base + T)) is its frame r - pad_base.  The few rows that
@@ -1047,6 +1052,9 @@ int pk_mi355_cmvn_apply(const pk_vector_t *global_stats, const pk_matrix_t *raw,
   if ((rc = ResizeHostMatrix(out, T > 0 ? kNumBins : 0, T))) return rc;
   if (T == 0) return 0;
   float *d_raw = nullptr, *d_g = nullptr, *d_yt = nullptr;
+  CmvnTables *d_ctab = nullptr;
+  CmvnTables ctab;
+  BuildCmvnTables(global_stats->data[kNumBins], &ctab);
   int64_t *d_i64 = nullptr;
   int32_t *d_T = nullptr;
   int64_t zeros[2] = {0, 0};
@@ -1057,18 +1065,20 @@ int pk_mi355_cmvn_apply(const pk_vector_t *global_stats, const pk_matrix_t *raw,
   auto step = [&](hipError_t x) { if (e == hipSuccess) e = x; };
   step(hipMalloc(&d_raw, sizeof(float) * (size_t)T * kNumBins));
   step(hipMalloc(&d_g, sizeof(float) * (kNumBins + 1)));
+  step(hipMalloc(&d_ctab, sizeof(CmvnTables)));
   step(hipMalloc(&d_yt, sizeof(float) * ld * kNumBins));
   step(hipMalloc(&d_i64, sizeof(int64_t) * 2));
   step(hipMalloc(&d_T, sizeof(int32_t)));
   if (e == hipSuccess) {
     step(hipMemcpy(d_raw, raw->data, sizeof(float) * (size_t)T * kNumBins, hipMemcpyHostToDevice));
     step(hipMemcpy(d_g, global_stats->data, sizeof(float) * (kNumBins + 1), hipMemcpyHostToDevice));
+    step(hipMemcpy(d_ctab, &ctab, sizeof(CmvnTables), hipMemcpyHostToDevice));
     step(hipMemcpy(d_i64, zeros, sizeof(zeros), hipMemcpyHostToDevice));
     step(hipMemcpy(d_T, &hT, sizeof(hT), hipMemcpyHostToDevice));
   }
   if (e == hipSuccess) {
     UttLayout lay{d_i64, d_T, d_i64, d_i64 + 1};
-    LaunchCmvn(d_raw, lay, 1, d_g, 0, 0, d_yt, ld, nullptr);
+    LaunchCmvn(d_raw, lay, 1, d_g, d_ctab, 0, 0, d_yt, ld, nullptr);
     step(hipGetLastError());
     step(hipMemcpy2D(tmp.data(), sizeof(float) * T, d_yt, sizeof(float) * ld, sizeof(float) * T, kNumBins,
                      hipMemcpyDeviceToHost));
@@ -1078,7 +1088,7 @@ int pk_mi355_cmvn_apply(const pk_vector_t *global_stats, const pk_matrix_t *raw,
   else
     for (int t = 0; t < T; ++t)
       for (int d = 0; d < kNumBins; ++d) out->data[(size_t)t * kNumBins + d] = tmp[(size_t)d * T + t];
-  hipFree(d_raw); hipFree(d_g); hipFree(d_yt); hipFree(d_i64); hipFree(d_T);
+  hipFree(d_raw); hipFree(d_g); hipFree(d_ctab); hipFree(d_yt); hipFree(d_i64); hipFree(d_T);
   return ret;
 }
 

@@ -239,9 +239,13 @@ __global__ __launch_bounds__(kWave) void FbankKernel(const SampleT *__restrict__
 }
 
 // One lane per (utterance, feature); lanes walk the frames in order because the
-// running window sum is rounded to float every frame (cmvn.cc:66-70).
+// running window sum is rounded to float every frame (cmvn.cc:66-70).  The window
+// count is min(t + 1, 600), so the smoothing weight and the 1/count scale come from
+// the host-built CmvnTables; the serial chain per frame is one fp64 add (two once the
+// window slides), one narrowing, two float multiply-adds.
 __global__ __launch_bounds__(kWave) void CmvnKernel(const float *__restrict__ raw, UttLayout utts,
-                                                    const float *__restrict__ g, int left,
+                                                    const float *__restrict__ g,
+                                                    const CmvnTables *__restrict__ tab, int left,
                                                     int right, float *__restrict__ yt,
                                                     int64_t ldy) {
   const int d = threadIdx.x;
@@ -253,53 +257,48 @@ __global__ __launch_bounds__(kWave) void CmvnKernel(const float *__restrict__ ra
   float *y0 = yt + (int64_t)d * ldy + utts.pad_base[utt];
 
   const float gd = g[d];
-  const double global_count = g[kNumBins];
   float s = 0.0f;      // cached window sum of this feature
-  float cnt = 0.0f;    // cached window count
   float y = 0.0f;
-  constexpr int kStage = 8;   // frames fetched ahead of the serial recurrence
-  float xs[kStage], xps[kStage];
-  for (int t = 0; t < T; ++t) {
-    const int slot = t % kStage;
-    if (slot == 0) {
-      // the loads do not depend on the recurrence: issue a block of them together
+  constexpr int kStage = 8;   // frames per block of loads; the next block is in flight
+                              // while the serial recurrence walks the current one
+  float xs[kStage], xps[kStage], al[kStage], ns[kStage];
+  float nxs[kStage], nxps[kStage], nal[kStage], nns[kStage];
+  auto fetch = [&](int t0, float (&a)[kStage], float (&b)[kStage], float (&c)[kStage],
+                   float (&e)[kStage]) {
+    // none of these loads depends on the recurrence
 #pragma unroll
-      for (int u = 0; u < kStage; ++u) {
-        const int tt = t + u;
-        xs[u] = tt < T ? x0[(int64_t)tt * kNumBins] : 0.0f;
-        xps[u] = (tt < T && tt >= kCmvnWindow) ? x0[(int64_t)(tt - kCmvnWindow) * kNumBins] : 0.0f;
+    for (int u = 0; u < kStage; ++u) {
+      const int t = t0 + u;
+      const int tt = t < kCmvnWindow ? t : kCmvnWindow - 1;
+      a[u] = t < T ? x0[(int64_t)t * kNumBins] : 0.0f;
+      b[u] = (t < T && t >= kCmvnWindow) ? x0[(int64_t)(t - kCmvnWindow) * kNumBins] : 0.0f;
+      c[u] = tab->alpha[tt];
+      e[u] = tab->neg_scale[tt];
+    }
+  };
+  fetch(0, xs, xps, al, ns);
+  for (int t0 = 0; t0 < T; t0 += kStage) {
+    fetch(t0 + kStage, nxs, nxps, nal, nns);
+#pragma unroll
+    for (int u = 0; u < kStage; ++u) {
+      const int t = t0 + u;
+      if (t < T) {
+        const float x = xs[u];
+        double acc = s;                                 // cmvn.cc:44-52
+        acc += x;
+        if (t >= kCmvnWindow) acc += -1.0 * static_cast<double>(xps[u]);   // cmvn.cc:58-64
+        s = static_cast<float>(acc);                    // cmvn.cc:66-70
+        float st = s;
+        if (t + 1 < kCmvnWindow) st += al[u] * gd;      // cmvn.cc:73-92 (count < window)
+        y = x;
+        y += ns[u] * st;                                // cmvn.cc:94-101
+        y0[left + t] = y;
+        if (t == 0)
+          for (int p = 0; p < left; ++p) y0[p] = y;     // am.cc:73 clamp, done at write time
       }
     }
-    float x = xs[0], xp = xps[0];
 #pragma unroll
-    for (int u = 1; u < kStage; ++u)
-      if (slot == u) { x = xs[u]; xp = xps[u]; }
-    double acc = s, accn = cnt;                      // cmvn.cc:44-52
-    acc += x;
-    accn += 1.0;
-    if (t >= kCmvnWindow) {                          // cmvn.cc:58-64
-      acc += -1.0 * static_cast<double>(xp);
-      accn -= 1.0;
-    }
-    s = static_cast<float>(acc);                     // cmvn.cc:66-70
-    cnt = static_cast<float>(accn);
-
-    float st = s, ct = cnt;                          // cmvn.cc:73-92
-    const double count = ct;
-    if (count < kCmvnWindow) {
-      double from_global = kCmvnWindow - count;
-      if (from_global > kCmvnGlobalFrames) from_global = kCmvnGlobalFrames;
-      const float alpha = static_cast<float>(from_global / global_count);
-      st += alpha * gd;
-      ct += alpha * g[kNumBins];
-    }
-    const float scale = static_cast<float>(1 / static_cast<double>(ct));   // cmvn.cc:94-101
-    const float ns = -scale;
-    y = x;
-    y += ns * st;
-    y0[left + t] = y;
-    if (t == 0)
-      for (int p = 0; p < left; ++p) y0[p] = y;      // am.cc:73 clamp, done at write time
+    for (int u = 0; u < kStage; ++u) { xs[u] = nxs[u]; xps[u] = nxps[u]; al[u] = nal[u]; ns[u] = nns[u]; }
   }
   for (int p = 0; p < right; ++p) y0[left + T + p] = y;   // am.cc:74
 }
@@ -336,10 +335,11 @@ void LaunchFbank(const float *wave_f32, const int16_t *wave_i16, const UttLayout
 }
 
 void LaunchCmvn(const float *raw, const UttLayout &utts, int num_utts, const float *d_global41,
-                int left, int right, float *yt, int64_t ldy, hipStream_t stream) {
+                const CmvnTables *d_cmvn_tab, int left, int right, float *yt, int64_t ldy,
+                hipStream_t stream) {
   if (num_utts <= 0) return;
   hipLaunchKernelGGL(CmvnKernel, dim3(num_utts), dim3(kWave), 0, stream, raw, utts, d_global41,
-                     left, right, yt, ldy);
+                     d_cmvn_tab, left, right, yt, ldy);
 }
 
 void LaunchPadTranspose(const float *feats, int T, int dim, int left, int right, float *yt,

@@ -30,7 +30,8 @@ void LaunchFbank(const float *wave_f32, const int16_t *wave_i16, const UttLayout
 // its frame t at column pad_base[u]+left+t, the first/last frame replicated into
 // the left/right pad (the clamp of am.cc:73-75 done once, at write time).
 void LaunchCmvn(const float *raw, const UttLayout &utts, int num_utts, const float *d_global41,
-                int left, int right, float *yt, int64_t ldy, hipStream_t stream);
+                const CmvnTables *d_cmvn_tab, int left, int right, float *yt, int64_t ldy,
+                hipStream_t stream);
 
 // Already-normalised features [T][dim] (frame-major) -> padded feature-major Yt.
 void LaunchPadTranspose(const float *feats, int T, int dim, int left, int right, float *yt,

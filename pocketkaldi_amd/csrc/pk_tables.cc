@@ -145,4 +145,22 @@ int BuildFrontendTables(FrontendTables *t) {
   return 0;
 }
 
+void BuildCmvnTables(float global_count_f, CmvnTables *t) {
+  const double global_count = global_count_f;
+  for (int i = 0; i < kCmvnWindow; ++i) {
+    float cnt = static_cast<float>(i + 1);
+    float alpha = 0.0f;
+    const double count = cnt;
+    if (count < kCmvnWindow) {                       // cmvn.cc:80-91
+      double from_global = kCmvnWindow - count;
+      if (from_global > kCmvnGlobalFrames) from_global = kCmvnGlobalFrames;
+      alpha = static_cast<float>(from_global / global_count);
+      cnt += alpha * global_count_f;                 // the count element of the float axpy
+    }
+    const float scale = static_cast<float>(1 / static_cast<double>(cnt));   // cmvn.cc:99
+    t->alpha[i] = alpha;
+    t->neg_scale[i] = -scale;
+  }
+}
+
 }  // namespace pkmi

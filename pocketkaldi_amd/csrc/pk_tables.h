@@ -55,6 +55,17 @@ struct FrontendTables {
 // Returns 0 on success.  Pure host code, no HIP.
 int BuildFrontendTables(FrontendTables *t);
 
+// CMVN per-frame scalars.  The window count after frame t is min(t + 1, 600) exactly, so
+// the smoothing weight (cmvn.cc:73-92) and the 1/count scale (cmvn.cc:94-101) -- both
+// formed in double and narrowed to float in the reference -- depend on t only.  They are
+// tabulated on the host with the reference's arithmetic: alpha[t] (0 once the window is
+// full) and neg_scale[t] = -float(1 / double(count_t + alpha[t] * global_count)).
+struct CmvnTables {
+  float alpha[kCmvnWindow];
+  float neg_scale[kCmvnWindow];
+};
+void BuildCmvnTables(float global_count, CmvnTables *t);
+
 }  // namespace pkmi
 
 #endif  // PK_TABLES_H_
