@@ -28,6 +28,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+FP16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
 def measured_traffic():
@@ -71,6 +72,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=10.0, help="audio per utterance")
     ap.add_argument("--model", default="S", choices=["S", "W", "tiny"])
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
+                    help="f32: bit-exact fp32 MFMA (default); f16x3: split-fp16 on the fp16 matrix cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-utts", type=int, default=64, help="utterances in the CPU-baseline sample (~15-20 s of CPU)")
     args = ap.parse_args()
@@ -98,7 +101,7 @@ def main():
         layers = [(l[0], np.zeros_like(l[1]), np.zeros_like(l[2])) if l[0] == "linear" else l
                   for l in layers]
         prior = np.full_like(prior, 1.0)
-    am = pk.AcousticModel(layers, prior, L, R)
+    am = pk.AcousticModel(layers, prior, L, R, precision=args.precision)
     import torch.distributed as tdist
     if world > 1 or tdist.is_initialized():
         ptr, nbytes = am.blob()
@@ -149,21 +152,25 @@ def main():
         flops_per_step = am.flops_per_frame() * frames_per_step
         achieved = flops_per_step / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         hidden, nh, pdfs = synth.MODELS[args.model]
+        peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "f32" else FP16_MFMA_PEAK_TFLOPS
         out = {
             "metric": "acoustic frames/sec (fbank->nnet log-likelihoods)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "f32" else "f16x3 (fp16 hi+lo operands, 3 MFMA per product, f32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "%d utterances x %.0f s 16 kHz per GPU (BASELINE configs[2]; x8 = configs[3]), "
                                    "440 -> %d x %d ReLU -> %d softmax, fbank+CMVN+nnet, PCM resident in HBM"
                                    % (args.batch, args.seconds, nh, hidden, pdfs),
                        "model": args.model, "utterances_per_gpu": args.batch,
                        "frames_per_gpu_per_step": int(frames_per_step),
                        "parallelism": "utterance-sharded x%d, weights broadcast once (RCCL)" % world},
-            "roofline": {"bound": "mfma", "kernel": "GemmKernel (fp32 MFMA affine layers, %d launches/step)" % gemm_launches,
-                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma",
+                         "kernel": ("GemmKernel (fp32 MFMA affine layers, %d launches/step)" if args.precision == "f32" else
+                                    "GemmF16Kernel (fp16 MFMA, 3 MFMA per algorithmic product, %d launches/step)") % gemm_launches,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak,
                          "flop_per_frame": am.flops_per_frame(),
                          "kernel_ms_per_step": gemm_ms,
                          "algorithmic_bytes_per_launch": None, "traffic": None},
@@ -179,7 +186,7 @@ def main():
             gbs = bpf * frames_per_step / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             out["stage_roofline"][k] = {"bound": "hbm", "bytes_per_frame": bpf, "achieved": gbs,
                                         "peak": hbm_peak, "unit": "GB/s", "frac": gbs / hbm_peak}
-        if args.model == "S" and args.batch == 256 and gemm_launches:
+        if args.model == "S" and args.batch == 256 and gemm_launches and args.precision == "f32":
             out["roofline"]["traffic"] = measured_traffic()
             # operands read once + output written once, averaged over the launches of a step
             # (layer 1 reads the 40-dim features, the splice is a view)

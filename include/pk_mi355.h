@@ -105,6 +105,16 @@ int pk_mi355_am_add_linear(pk_mi355_am_t *am, int in_dim, int out_dim, const flo
 /* ReLULayer / NormalizeLayer / SoftmaxLayer, nnet.cc:38-75                       */
 int pk_mi355_am_add_layer(pk_mi355_am_t *am, int layer_type);
 
+/* Arithmetic of the affine layers (set before finalize / read; default F32).
+ *   F32   : fp32 MFMA, accumulation order of the reference's SGEMM -- bit-identical layers.
+ *   F16X3 : every fp32 operand carried as an fp16 (hi, lo) pair, three fp16 MFMAs per
+ *           product, fp32 accumulation: ~1e-6 relative on log-likelihoods (inside the
+ *           1e-4 contract, not bit-exact), several times faster.  Supports
+ *           (Linear [ReLU])+ [Softmax] networks; |values| above 65504 saturate.        */
+enum { PK_MI355_PRECISION_F32 = 0, PK_MI355_PRECISION_F16X3 = 1 };
+int pk_mi355_am_set_precision(pk_mi355_am_t *am, int precision);
+int pk_mi355_am_precision(const pk_mi355_am_t *am);
+
 /* AcousticModel::Read tail, am.cc:41-60: prior holds probabilities (the log is
  * taken here); tid2pdf is indexed by transition-id.  tid2pdf may be NULL (then
  * pk_decodable_loglikelihood treats trans_id as the pdf index).  Uploads the

@@ -54,7 +54,7 @@ EXPORTS = [
     "pk_mi355_last_error", "pk_mi355_set_device", "pk_decodable_init", "pk_decodable_destroy",
     "pk_decodable_loglikelihood", "pk_decodable_islastframe", "pk_mi355_am_create",
     "pk_mi355_am_destroy", "pk_mi355_am_add_linear", "pk_mi355_am_add_layer",
-    "pk_mi355_am_finalize", "pk_mi355_am_read", "pk_mi355_am_num_pdfs", "pk_mi355_am_input_dim",
+    "pk_mi355_am_finalize", "pk_mi355_am_set_precision", "pk_mi355_am_precision", "pk_mi355_am_read", "pk_mi355_am_num_pdfs", "pk_mi355_am_input_dim",
     "pk_mi355_am_transition_to_pdf", "pk_mi355_am_blob_device_ptr", "pk_mi355_am_blob_bytes",
     "pk_mi355_nnet_propagate", "pk_mi355_num_frames", "pk_mi355_fbank_compute",
     "pk_mi355_cmvn_apply", "pk_mi355_batch_create", "pk_mi355_batch_destroy",
@@ -101,6 +101,8 @@ def lib():
     L.pk_mi355_am_destroy.argtypes = [C.c_void_p]
     L.pk_mi355_am_add_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, f32p]
     L.pk_mi355_am_add_layer.argtypes = [C.c_void_p, C.c_int]
+    L.pk_mi355_am_set_precision.argtypes = [C.c_void_p, C.c_int]
+    L.pk_mi355_am_precision.argtypes = [C.c_void_p]
     L.pk_mi355_am_finalize.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, i32p, C.c_int]
     L.pk_mi355_am_read.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int,
                                    C.c_int]
@@ -223,10 +225,13 @@ class AcousticModel:
     """
     _KIND = {"relu": RELU, "normalize": NORMALIZE, "softmax": SOFTMAX}
 
+    PRECISIONS = {"f32": 0, "f16x3": 1}
+
     def __init__(self, layers=None, prior=None, left_context=0, right_context=0, tid2pdf=None,
-                 num_pdfs=None):
+                 num_pdfs=None, precision="f32"):
         L = lib()
         self._h = L.pk_mi355_am_create()
+        _check(L.pk_mi355_am_set_precision(self._h, self.PRECISIONS[precision]))
         if layers is not None:
             for l in layers:
                 if l[0] == "linear":
@@ -243,9 +248,10 @@ class AcousticModel:
                 0 if tid is None else tid.shape[0]))
 
     @classmethod
-    def read(cls, nnet_path, prior_path, tid2pdf_path, left_context, right_context, num_pdfs):
+    def read(cls, nnet_path, prior_path, tid2pdf_path, left_context, right_context, num_pdfs,
+             precision="f32"):
         """AcousticModel::Read (am.cc:23-63) from the converted model files."""
-        self = cls()
+        self = cls(precision=precision)
         _check(lib().pk_mi355_am_read(self._h, nnet_path.encode(), prior_path.encode(),
                                       None if tid2pdf_path is None else tid2pdf_path.encode(),
                                       left_context, right_context, num_pdfs))

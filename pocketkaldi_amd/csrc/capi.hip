@@ -152,6 +152,7 @@ struct HostLayer {
 struct DevLinear {
   int K = 0, N = 0, Kpad = 0, Npad = 0;
   size_t wt_off = 0, b_off = 0;    // float offsets into the blob
+  size_t wl_off = 0;               // f16x3 mode: wt_off = W hi, wl_off = W lo ([Npad][Kpad] halves)
 };
 
 struct Workspace;   // forward
@@ -160,6 +161,7 @@ struct pk_mi355_am {
   int device = 0;
   std::vector<HostLayer> layers;
   bool finalized = false;
+  int precision = PK_MI355_PRECISION_F32;
   int left = 0, right = 0, num_pdfs = 0;
   int input_dim = 0, output_dim = 0, feat_dim = 0;
   int max_dim_pad = 0;             // widest activation, rounded to the tile
@@ -181,10 +183,28 @@ struct ExecBufs {
   float *b = nullptr;     // pong
   int64_t rows_cap = 0;
   int64_t in_floats = 0, act_floats = 0;
+  // f16x3 mode: (hi, lo) activation pairs [rows_cap][max Npad], ping/pong; the plain
+  // input pair [rows_cap][Kpad0]; `a` holds the fp32 logits, `b` softmax probabilities
+  _Float16 *h[2] = {nullptr, nullptr}, *l[2] = {nullptr, nullptr};
+  _Float16 *xin_h = nullptr, *xin_l = nullptr;
 };
 
 int AllocExec(const pk_mi355_am *am, int64_t rows_cap, ExecBufs *e) {
   e->rows_cap = rows_cap;
+  if (am->precision == PK_MI355_PRECISION_F16X3) {
+    const size_t act = sizeof(_Float16) * (size_t)am->max_dim_pad * rows_cap;
+    const size_t xin = sizeof(_Float16) * (size_t)RoundUp(am->input_dim, kBKF16) * (rows_cap + 16);
+    for (int i = 0; i < 2; ++i) {
+      HIP_TRY(hipMalloc(&e->h[i], act));
+      HIP_TRY(hipMalloc(&e->l[i], act));
+      HIP_TRY(hipMemset(e->h[i], 0, act));
+      HIP_TRY(hipMemset(e->l[i], 0, act));
+    }
+    HIP_TRY(hipMalloc(&e->xin_h, xin));
+    HIP_TRY(hipMalloc(&e->xin_l, xin));
+    HIP_TRY(hipMemset(e->xin_h, 0, xin));
+    HIP_TRY(hipMemset(e->xin_l, 0, xin));
+  }
   e->act_floats = (int64_t)am->max_dim_pad * rows_cap;
   e->in_floats = RoundUp(am->input_dim, kBK) * rows_cap;
   HIP_TRY(hipMalloc(&e->a, e->act_floats * sizeof(float)));
@@ -200,6 +220,9 @@ void FreeExec(ExecBufs *e) {
   hipFree(e->a);
   hipFree(e->b);
   hipFree(e->in);
+  for (int i = 0; i < 2; ++i) { hipFree(e->h[i]); hipFree(e->l[i]); }
+  hipFree(e->xin_h);
+  hipFree(e->xin_l);
   *e = ExecBufs();
 }
 
@@ -348,6 +371,65 @@ int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t
   return 0;
 }
 
+// f16x3 mode: the same layer walk on (hi, lo) fp16 pairs, everything frame-major.
+// Input: xh/xl [rows][ldx] (ldx = feat_dim for the spliced view of the CMVN output,
+// row r = frames r .. r+L+R, am.cc:65-88; or the padded plain input).  Finalize has
+// already checked the layer pattern: (Linear [ReLU])+ [Softmax].
+int RunLayersF16(const pk_mi355_am *am, const ExecBufs &e, const _Float16 *xh, const _Float16 *xl,
+                 int64_t ldx, int rows, bool want_tail, float scale, float *tail_out,
+                 int64_t tail_ld, hipStream_t stream, Timer *timer, ExecResult *res) {
+  const int rows_pad = (int)RoundUp(rows, kTileF16);
+  if (rows_pad > e.rows_cap) return Fail(PK_MI355_E_INVALID, "chunk larger than workspace");
+  const float *blob = am->d_blob;
+  const int nl = (int)am->layers.size();
+  const int nlin = (int)am->lin.size();
+  int li = 0, buf = 0;
+  int64_t out_ld = 0;
+  for (int i = 0; i < nl; ++i) {
+    if (am->layers[i].type != PK_NNET_LINEAR_LAYER) continue;
+    const DevLinear &D = am->lin[li];
+    const bool last = (li == nlin - 1);
+    GemmF16Args g;
+    g.Xh = xh; g.Xl = xl; g.ldx = ldx;
+    g.Wh = reinterpret_cast<const _Float16 *>(blob + D.wt_off);
+    g.Wl = reinterpret_cast<const _Float16 *>(blob + D.wl_off);
+    g.ldw = D.Kpad;
+    g.K = D.Kpad;
+    g.bias = blob + D.b_off;
+    g.relu = (i + 1 < nl && am->layers[i + 1].type == PK_NNET_RELU_LAYER) ? 1 : 0;
+    g.out_f32 = last ? e.a : nullptr;
+    g.out_hi = last ? nullptr : e.h[buf];
+    g.out_lo = last ? nullptr : e.l[buf];
+    g.ldo = D.Npad;
+    g.tiles_m = rows_pad / kTileF16;
+    g.tiles_n = D.Npad / kTileF16;
+    {
+      Scoped t(timer, PK_MI355_K_GEMM, stream);
+      LaunchGemmF16(g, stream);
+    }
+    xh = e.h[buf]; xl = e.l[buf]; ldx = D.Npad;
+    out_ld = D.Npad;
+    buf ^= 1;
+    ++li;
+  }
+  const int dim = am->output_dim;
+  const bool softmax_last = am->layers.back().type == PK_NNET_SOFTMAX_LAYER;
+  const float *cur = e.a;
+  if (want_tail) {
+    Scoped t(timer, PK_MI355_K_TAIL, stream);
+    LaunchTail(softmax_last ? kTailSoftmaxLoglik : kTailLoglik, cur, out_ld, rows, dim,
+               blob + am->logprior_off, scale, tail_out, tail_ld, stream);
+  } else if (softmax_last) {
+    Scoped t(timer, PK_MI355_K_TAIL, stream);
+    LaunchTail(kTailSoftmaxProb, cur, out_ld, rows_pad, dim, nullptr, 1.0f, e.b, out_ld, stream);
+    cur = e.b;
+  }
+  if (res) { res->data = cur; res->ld = out_ld; res->dim = dim; }
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) return Fail(PK_MI355_E_DEVICE, "kernel launch failed: %s", hipGetErrorString(le));
+  return 0;
+}
+
 }  // namespace
 
 // Single-utterance workspace used by pk_decodable_init / nnet_propagate.
@@ -355,6 +437,7 @@ struct Workspace {
   ExecBufs exec;
   float *d_feats = nullptr;  int64_t feats_cap = 0;     // frame-major host upload
   float *d_yt = nullptr;     int64_t yt_ld = 0;          // [feat_dim][yt_ld]
+  _Float16 *d_yh = nullptr, *d_yl = nullptr;            // f16x3: [yt_ld][feat_dim] (hi, lo)
   float *d_out = nullptr;    int64_t out_cap = 0;        // [rows][num_pdfs]
   hipStream_t stream = nullptr;
 };
@@ -384,6 +467,12 @@ int EnsureWorkspace(pk_mi355_am *am, int64_t frames, int width) {
     w->yt_ld = need_ld;
     HIP_TRY(hipMalloc(&w->d_yt, sizeof(float) * w->yt_ld * am->feat_dim));
     HIP_TRY(hipMemset(w->d_yt, 0, sizeof(float) * w->yt_ld * am->feat_dim));
+    if (am->precision == PK_MI355_PRECISION_F16X3) {
+      hipFree(w->d_yh);
+      hipFree(w->d_yl);
+      HIP_TRY(hipMalloc(&w->d_yh, sizeof(_Float16) * w->yt_ld * am->feat_dim));
+      HIP_TRY(hipMalloc(&w->d_yl, sizeof(_Float16) * w->yt_ld * am->feat_dim));
+    }
   }
   const int64_t need_out = frames * std::max(am->output_dim, 1);
   if (need_out > w->out_cap) {
@@ -399,6 +488,8 @@ void FreeWorkspace(Workspace *w) {
   FreeExec(&w->exec);
   hipFree(w->d_feats);
   hipFree(w->d_yt);
+  hipFree(w->d_yh);
+  hipFree(w->d_yl);
   hipFree(w->d_out);
   if (w->stream) hipStreamDestroy(w->stream);
   delete w;
@@ -481,6 +572,16 @@ int pk_mi355_am_add_layer(pk_mi355_am_t *am, int layer_type) {
   return 0;
 }
 
+int pk_mi355_am_set_precision(pk_mi355_am_t *am, int precision) {
+  if (!am || am->finalized) return Fail(PK_MI355_E_STATE, "set the precision before finalizing the model");
+  if (precision != PK_MI355_PRECISION_F32 && precision != PK_MI355_PRECISION_F16X3)
+    return Fail(PK_MI355_E_INVALID, "unknown precision %d", precision);
+  am->precision = precision;
+  return 0;
+}
+
+int pk_mi355_am_precision(const pk_mi355_am_t *am) { return am ? am->precision : 0; }
+
 int pk_mi355_am_finalize(pk_mi355_am_t *am, const float *prior, int num_pdfs, int left_context,
                          int right_context, const int32_t *tid2pdf, int num_tids) {
   if (!am || am->finalized) return Fail(PK_MI355_E_STATE, "model already finalized");
@@ -489,6 +590,20 @@ int pk_mi355_am_finalize(pk_mi355_am_t *am, const float *prior, int num_pdfs, in
   if (rc) return rc;
 
   // dimension chain
+  const bool f16 = am->precision == PK_MI355_PRECISION_F16X3;
+  if (f16) {
+    // the split-fp16 path covers the BASELINE model family: (Linear [ReLU])+ [Softmax]
+    const int nl = (int)am->layers.size();
+    bool ok = nl > 0 && am->layers[0].type == PK_NNET_LINEAR_LAYER;
+    for (int i = 0; ok && i < nl; ++i) {
+      const int t = am->layers[i].type;
+      if (t == PK_NNET_RELU_LAYER) ok = i > 0 && am->layers[i - 1].type == PK_NNET_LINEAR_LAYER;
+      else if (t == PK_NNET_SOFTMAX_LAYER) ok = (i == nl - 1);
+      else if (t != PK_NNET_LINEAR_LAYER) ok = false;
+    }
+    if (ok && am->layers.back().type == PK_NNET_RELU_LAYER && nl >= 2) ok = true;
+    if (!ok) return Fail(PK_MI355_E_INVALID, "f16x3 precision supports (Linear [ReLU])+ [Softmax] networks only");
+  }
   int first_in = 0, dim = 0;
   am->lin.clear();
   am->flops_per_frame = 0;
@@ -502,14 +617,22 @@ int pk_mi355_am_finalize(pk_mi355_am_t *am, const float *prior, int num_pdfs, in
     dim = L.out_dim;
     DevLinear D;
     D.K = L.in_dim; D.N = L.out_dim;
-    D.Kpad = (int)RoundUp(D.K, kBK);
-    D.Npad = (int)RoundUp(D.N, kTile);
-    D.wt_off = off; off += (size_t)D.Kpad * D.Npad;
+    if (f16) {
+      D.Kpad = (int)RoundUp(D.K, kBKF16);
+      D.Npad = (int)RoundUp(D.N, kTileF16);
+      const size_t wfloats = (size_t)D.Kpad * D.Npad / 2;     // halves -> float units
+      D.wt_off = off; off += wfloats;
+      D.wl_off = off; off += wfloats;
+    } else {
+      D.Kpad = (int)RoundUp(D.K, kBK);
+      D.Npad = (int)RoundUp(D.N, kTile);
+      D.wt_off = off; off += (size_t)D.Kpad * D.Npad;
+    }
     D.b_off = off;  off += D.Npad;
     am->lin.push_back(D);
     am->flops_per_frame += 2.0 * D.K * D.N;
     max_pad = std::max(max_pad, D.Npad);
-    max_pad = std::max(max_pad, (int)RoundUp(D.K, kTile));
+    max_pad = std::max(max_pad, (int)RoundUp(D.K, f16 ? kTileF16 : kTile));
   }
   if (am->lin.empty()) {
     // layer-only networks (the nnet_test.cc micro-tests): the width is the pdf count
@@ -540,9 +663,23 @@ int pk_mi355_am_finalize(pk_mi355_am_t *am, const float *prior, int num_pdfs, in
   for (auto &L : am->layers) {
     if (L.type != PK_NNET_LINEAR_LAYER) continue;
     const DevLinear &D = am->lin[li++];
-    float *wt = blob.data() + D.wt_off;
-    for (int o = 0; o < D.N; ++o)
-      for (int k = 0; k < D.K; ++k) wt[(size_t)k * D.Npad + o] = L.W[(size_t)o * D.K + k];
+    if (f16) {
+      // W stays [out][in] (k contiguous), split into fp16 hi / lo = fp16(w - hi)
+      _Float16 *wh = reinterpret_cast<_Float16 *>(blob.data() + D.wt_off);
+      _Float16 *wl = reinterpret_cast<_Float16 *>(blob.data() + D.wl_off);
+      for (int o = 0; o < D.N; ++o)
+        for (int k = 0; k < D.K; ++k) {
+          float v = L.W[(size_t)o * D.K + k];
+          v = std::min(std::max(v, -65504.0f), 65504.0f);
+          const _Float16 hi = static_cast<_Float16>(v);
+          wh[(size_t)o * D.Kpad + k] = hi;
+          wl[(size_t)o * D.Kpad + k] = static_cast<_Float16>(v - static_cast<float>(hi));
+        }
+    } else {
+      float *wt = blob.data() + D.wt_off;
+      for (int o = 0; o < D.N; ++o)
+        for (int k = 0; k < D.K; ++k) wt[(size_t)k * D.Npad + o] = L.W[(size_t)o * D.K + k];
+    }
     memcpy(blob.data() + D.b_off, L.b.data(), sizeof(float) * D.N);
   }
   for (int i = 0; i < dim; ++i)
@@ -629,10 +766,17 @@ int pk_mi355_nnet_propagate(pk_mi355_am_t *am, const pk_matrix_t *in, pk_matrix_
   HIP_TRY(hipMemcpyAsync(w->d_feats, in->data, sizeof(float) * (size_t)T * D, hipMemcpyHostToDevice, w->stream));
   for (int64_t r0 = 0; r0 < T; r0 += kSingleChunk) {
     const int rows = (int)std::min<int64_t>(kSingleChunk, T - r0);
-    LaunchTransposeToCols(w->d_feats + r0 * D, D, rows, D, w->exec.in, w->exec.rows_cap, w->stream);
     ExecResult res;
-    if ((rc = RunLayers(am, w->exec, nullptr, 0, 0, rows, false, 1.0f, nullptr, 0, w->stream, nullptr, &res)))
-      return rc;
+    if (am->precision == PK_MI355_PRECISION_F16X3) {
+      const int kp = (int)RoundUp(D, kBKF16);
+      LaunchSplitF16(w->d_feats + r0 * D, D, 1, rows, D, kp, w->exec.xin_h, w->exec.xin_l, kp, w->stream);
+      rc = RunLayersF16(am, w->exec, w->exec.xin_h, w->exec.xin_l, kp, rows, false, 1.0f, nullptr, 0,
+                        w->stream, nullptr, &res);
+    } else {
+      LaunchTransposeToCols(w->d_feats + r0 * D, D, rows, D, w->exec.in, w->exec.rows_cap, w->stream);
+      rc = RunLayers(am, w->exec, nullptr, 0, 0, rows, false, 1.0f, nullptr, 0, w->stream, nullptr, &res);
+    }
+    if (rc) return rc;
     HIP_TRY(hipMemcpy2DAsync(out->data + r0 * am->output_dim, sizeof(float) * am->output_dim, res.data,
                              sizeof(float) * res.ld, sizeof(float) * am->output_dim, rows,
                              hipMemcpyDeviceToHost, w->stream));
@@ -663,11 +807,15 @@ void pk_decodable_init(pk_decodable_t *self, pk_mi355_am_t *am, float prob_scale
   hipError_t e = hipMemcpyAsync(w->d_feats, feats->data, sizeof(float) * (size_t)T * D, hipMemcpyHostToDevice, w->stream);
   if (e != hipSuccess) { dev_fail(e); return; }
   LaunchPadTranspose(w->d_feats, T, D, am->left, am->right, w->d_yt, w->yt_ld, 0, w->stream);
+  const bool f16 = am->precision == PK_MI355_PRECISION_F16X3;
+  if (f16) LaunchSplitF16(w->d_yt, 1, w->yt_ld, (int)w->yt_ld, D, D, w->d_yh, w->d_yl, D, w->stream);
   for (int64_t r0 = 0; r0 < T; r0 += kSingleChunk) {
     const int rows = (int)std::min<int64_t>(kSingleChunk, T - r0);
-    if (RunLayers(am, w->exec, w->d_yt + r0, w->yt_ld, D, rows, true, prob_scale, w->d_out + r0 * N, N,
-                  w->stream, nullptr, nullptr))
-      return;
+    const int rc = f16 ? RunLayersF16(am, w->exec, w->d_yh + r0 * D, w->d_yl + r0 * D, D, rows, true, prob_scale,
+                                      w->d_out + r0 * N, N, w->stream, nullptr, nullptr)
+                       : RunLayers(am, w->exec, w->d_yt + r0, w->yt_ld, D, rows, true, prob_scale,
+                                   w->d_out + r0 * N, N, w->stream, nullptr, nullptr);
+    if (rc) return;
   }
   float *host = static_cast<float *>(malloc(sizeof(float) * (size_t)T * N));   // util.cc:58-68 pk_alloc
   if (!host) { Fail(PK_MI355_E_INVALID, "out of host memory"); return; }
@@ -727,6 +875,7 @@ struct pk_mi355_batch {
   // stages
   float *d_raw = nullptr;   // [max_frames][40]
   float *d_yt = nullptr;    // [feat_dim][ldy]
+  _Float16 *d_yh = nullptr, *d_yl = nullptr;   // f16x3: [ldy][feat_dim] (hi, lo)
   int64_t ldy = 0;
   float *d_ll = nullptr;    // [max_cols][num_pdfs]
   ExecBufs exec;
@@ -794,11 +943,11 @@ pk_mi355_batch_t *pk_mi355_batch_create(pk_mi355_am_t *am, const float *global_s
   b->max_samples = max_total_samples;
   if (const char *c = getenv("PK_MI355_CHUNK")) {
     long v = atol(c);
-    if (v >= kTile) b->chunk = RoundUp(v, kTile);
+    if (v >= kTile) b->chunk = RoundUp(v, kTileF16);
   }
   const int pad = am->left + am->right;
   b->max_frames = max_total_samples / kFrameShift + max_utts;
-  b->max_cols = RoundUp(b->max_frames + (int64_t)max_utts * pad, kTile);
+  b->max_cols = RoundUp(b->max_frames + (int64_t)max_utts * pad, kTileF16);
   b->chunk = std::min<int64_t>(b->chunk, b->max_cols);
   b->ldy = RoundUp(b->max_cols, b->chunk) + 256;
   FrontendTables host;
@@ -821,6 +970,10 @@ pk_mi355_batch_t *pk_mi355_batch_create(pk_mi355_am_t *am, const float *global_s
   chk(hipMalloc(&b->d_raw, sizeof(float) * b->max_frames * kNumBins));
   chk(hipMalloc(&b->d_yt, sizeof(float) * b->ldy * kNumBins));
   if (ok) chk(hipMemset(b->d_yt, 0, sizeof(float) * b->ldy * kNumBins));
+  if (am->precision == PK_MI355_PRECISION_F16X3) {
+    chk(hipMalloc(&b->d_yh, sizeof(_Float16) * b->ldy * kNumBins));
+    chk(hipMalloc(&b->d_yl, sizeof(_Float16) * b->ldy * kNumBins));
+  }
   chk(hipMalloc(&b->d_ll, sizeof(float) * b->max_cols * am->num_pdfs));
   if (ok && AllocExec(am, b->chunk, &b->exec)) ok = false;
   if (!ok) { pk_mi355_batch_destroy(b); return nullptr; }
@@ -835,7 +988,7 @@ void pk_mi355_batch_destroy(pk_mi355_batch_t *b) {
   hipFree(b->d_tables); hipFree(b->d_global); hipFree(b->d_cmvn_tab);
   hipFree(b->d_wave); hipFree(b->d_wave_i16);
   hipFree(b->d_wave_off); hipFree(b->d_raw_base); hipFree(b->d_pad_base); hipFree(b->d_T);
-  hipFree(b->d_raw); hipFree(b->d_yt); hipFree(b->d_ll);
+  hipFree(b->d_raw); hipFree(b->d_yt); hipFree(b->d_yh); hipFree(b->d_yl); hipFree(b->d_ll);
   if (b->stream) hipStreamDestroy(b->stream);
   delete b;
 }
@@ -906,10 +1059,17 @@ int pk_mi355_batch_score(pk_mi355_batch_t *b, float prob_scale, int sync) {
   // [pad_base, pad_base + T)) is its frame r - pad_base.  The few rows that
   // straddle two utterances are computed and ignored.
   const int N = am->num_pdfs;
+  const bool f16 = am->precision == PK_MI355_PRECISION_F16X3;
+  if (f16) {
+    Scoped t(tm, PK_MI355_K_OTHER, b->stream);
+    LaunchSplitF16(b->d_yt, 1, b->ldy, (int)b->ldy, kNumBins, kNumBins, b->d_yh, b->d_yl, kNumBins, b->stream);
+  }
   for (int64_t c0 = 0; c0 < b->total_cols; c0 += b->chunk) {
     const int rows = (int)std::min<int64_t>(b->chunk, b->total_cols - c0);
-    rc = RunLayers(am, b->exec, b->d_yt + c0, b->ldy, kNumBins, rows, true, prob_scale,
-                   b->d_ll + c0 * N, N, b->stream, tm, nullptr);
+    rc = f16 ? RunLayersF16(am, b->exec, b->d_yh + c0 * kNumBins, b->d_yl + c0 * kNumBins, kNumBins, rows, true,
+                            prob_scale, b->d_ll + c0 * N, N, b->stream, tm, nullptr)
+             : RunLayers(am, b->exec, b->d_yt + c0, b->ldy, kNumBins, rows, true, prob_scale,
+                         b->d_ll + c0 * N, N, b->stream, tm, nullptr);
     if (rc) return rc;
   }
   b->scored = true;

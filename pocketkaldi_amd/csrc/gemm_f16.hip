@@ -1,0 +1,253 @@
+// gemm_f16.hip -- the affine layers on the fp16 matrix cores at fp32-class accuracy
+// ("f16x3" precision mode; the default mode is the bit-exact fp32 kernel in gemm.hip).
+//
+// Every fp32 operand is carried as a pair of fp16 values, x = hi + lo with
+// hi = fp16(x), lo = fp16(x - hi)   (x - hi is exact in fp32), and
+//
+//   D[m][n] = sum_k Xhi Whi + Xhi Wlo + Xlo Whi          (Xlo Wlo ~ 2^-22, dropped)
+//
+// three v_mfma_f32_32x32x16_f16 per 32 x 32 x 16 block into ONE fp32 accumulator
+// (fp16 products are exact in fp32; the cross terms sit 11 bits below the main term
+// and fit the accumulator).  Measured error vs the fp32 reference chain is ~1e-6
+// relative on log-likelihoods -- inside the 1e-4 contract, not bit-exact.  Range: fp16
+// saturates at 65504; the split clamps instead of overflowing.
+//
+// Layout (everything frame-major here): X = [rows][K] fp16 hi / lo (rows = frames, k
+// contiguous), W = [N][K] fp16 hi / lo -- the model file's own [out][in] order -- and
+// D = [rows][N].  Layer 1 reads the CMVN output [frames][40] with row stride 40 and
+// K = 440: the splice (am.cc:65-88) is again just an address function.
+//
+// Tile 256 x 256 per 512-thread workgroup (8 waves as 2 x 4, 128 x 64 per wave = 4 x 2
+// MFMA tiles, 128 accumulator registers), BK = 32, two 64 KiB LDS slabs, LDS-DMA
+// staging with the XOR swizzle on the SOURCE address (linear LDS destination) and the
+// same XOR on the ds_read_b128 fragment reads (conflict-free).  The two column
+// sub-tiles of a wave take interleaved columns so that an output row is written as
+// packed pairs (128 contiguous bytes of fp16, 256 of fp32 per store).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include "pk_kernels.h"
+
+namespace pkmi {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+typedef const __attribute__((address_space(1))) void *GlobalPtr;
+typedef __attribute__((address_space(3))) void *LdsPtr;
+
+constexpr int kT = kTileF16;                  // 256: tile edge
+constexpr int kBKh = 32;                      // k per slab (halves): 64-byte LDS rows
+constexpr int kThreadsF16 = 512;
+constexpr int kArrayBytes = kT * kBKh * 2;    // one operand array of one slab: 16 KiB
+constexpr int kSlabBytes = 4 * kArrayBytes;   // X hi, X lo, W hi, W lo: 64 KiB
+constexpr int kPiecesPerWave = 8;             // 64 x 1 KiB pieces per slab / 8 waves
+
+// LDS row (0..255) of the W tile -> column n of the tile.  Within each block of 64
+// columns sub-tile y of a wave owns columns 2 i' + y, stored as 32 consecutive LDS rows.
+__device__ __forceinline__ int WRowToCol(int row) {
+  return (row & ~63) + 2 * (row & 31) + ((row >> 5) & 1);
+}
+
+// byte offset of logical 16-byte chunk c (4 per 64-byte row) of LDS row `row`
+__device__ __forceinline__ int SwzOff(int row, int c) {
+  return row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+}
+
+struct SplitOut {
+  _Float16 hi, lo;
+};
+__device__ __forceinline__ SplitOut Split(float v) {
+  v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+  SplitOut s;
+  s.hi = static_cast<_Float16>(v);
+  s.lo = static_cast<_Float16>(v - static_cast<float>(s.hi));
+  return s;
+}
+
+template <bool RELU, bool LAST>
+__global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 slabs
+
+  // XCD-aware tile walk, as in gemm.hip: contiguous ids per XCD, 4 x 4 super-tiles
+  const int nblk = gridDim.x;                       // multiple of 8
+  const int b = blockIdx.x;
+  const int wg = (b % 8) * (nblk / 8) + b / 8;
+  const int super_m = (a.tiles_m + 3) / 4;
+  const int s = wg / 16, w = wg % 16;
+  const int tm = (s % super_m) * 4 + (w % 4);
+  const int tn = (s / super_m) * 4 + (w / 4);
+  if (tm >= a.tiles_m || tn >= a.tiles_n) return;
+  const int m0 = tm * kT, n0 = tn * kT;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;          // 2 x 4 waves
+  const int l31 = lane & 31, kg = lane >> 5;
+
+  // ---- DMA role of this lane: pieces 2 wave, 2 wave + 1 of each of the four arrays;
+  // a piece is 16 LDS rows, lane -> row (lane >> 2), stored chunk (lane & 3)
+  const _Float16 *src[2][4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int row = (wave * 2 + p) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);    // logical chunk landing at this lane's slot
+    const int64_t xoff = (int64_t)(m0 + row) * a.ldx + c * 8;
+    const int64_t woff = (int64_t)(n0 + WRowToCol(row)) * a.ldw + c * 8;
+    src[p][0] = a.Xh + xoff;
+    src[p][1] = a.Xl + xoff;
+    src[p][2] = a.Wh + woff;
+    src[p][3] = a.Wl + woff;
+  }
+  auto issue_slab = [&](int k0, int buf) {
+#pragma unroll
+    for (int arr = 0; arr < 4; ++arr)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        unsigned char *dst = smem + buf * kSlabBytes + arr * kArrayBytes + (wave * 2 + p) * 1024;
+        __builtin_amdgcn_global_load_lds((GlobalPtr)(src[p][arr] + k0), (LdsPtr)dst, 16, 0, 0);
+      }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) acc[x][y] = f32x16{0};
+
+  // fragment byte offsets inside one operand array, per k16 step ks (0, 1):
+  // A sub-tile x: LDS row wm*128 + 32x + l31; B sub-tile y: LDS row wn*64 + 32y + l31
+  int aoff[4][2], boff[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x) aoff[x][ks] = SwzOff(wm * 128 + 32 * x + l31, ks * 2 + kg);
+#pragma unroll
+    for (int y = 0; y < 2; ++y) boff[y][ks] = SwzOff(wn * 64 + 32 * y + l31, ks * 2 + kg);
+  }
+
+  const int nkt = a.K / kBKh;
+  issue_slab(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) issue_slab((kt + 1) * kBKh, buf ^ 1);   // the other slab was last read in kt-1
+    const unsigned char *base = smem + buf * kSlabBytes;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        ah[x] = *reinterpret_cast<const f16x8 *>(base + 0 * kArrayBytes + aoff[x][ks]);
+        al[x] = *reinterpret_cast<const f16x8 *>(base + 1 * kArrayBytes + aoff[x][ks]);
+      }
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        bh[y] = *reinterpret_cast<const f16x8 *>(base + 2 * kArrayBytes + boff[y][ks]);
+        bl[y] = *reinterpret_cast<const f16x8 *>(base + 3 * kArrayBytes + boff[y][ks]);
+      }
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[x], bl[y], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[x], bh[y], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[x], bh[y], acc[x][y], 0, 0, 0);
+        }
+    }
+    // next slab landed (own pieces; the barrier covers the other waves'), and every
+    // wave is done reading this one before it is overwritten in kt+1
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- epilogue: acc[x][y][r] = D[M0 + 32x + i'][N0 + 2 l31 + y],
+  // i' = (r & 3) + 8 (r >> 2) + 4 kg; bias (nnet.cc:32-35), ReLU (nnet.cc:56-58)
+  const int M0 = m0 + wm * 128, N0 = n0 + wn * 64 + 2 * l31;
+  const f32x2 bias = *reinterpret_cast<const f32x2 *>(a.bias + N0);
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = M0 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * kg;
+      float v0 = acc[x][0][r] + bias[0], v1 = acc[x][1][r] + bias[1];
+      if (RELU) {
+        v0 = v0 < 0.0f ? 0.0f : v0;
+        v1 = v1 < 0.0f ? 0.0f : v1;
+      }
+      if (LAST) {
+        *reinterpret_cast<f32x2 *>(a.out_f32 + (int64_t)m * a.ldo + N0) = f32x2{v0, v1};
+      } else {
+        const SplitOut s0 = Split(v0), s1 = Split(v1);
+        *reinterpret_cast<f16x2 *>(a.out_hi + (int64_t)m * a.ldo + N0) = f16x2{s0.hi, s1.hi};
+        *reinterpret_cast<f16x2 *>(a.out_lo + (int64_t)m * a.ldo + N0) = f16x2{s0.lo, s1.lo};
+      }
+    }
+}
+
+// fp32 -> (hi, lo) fp16 pairs.  in: element (r, c) at in[r * stride_r + c * stride_c];
+// out: [rows][ld_out] frame-major, columns >= cols zero-filled up to cols_pad.
+__global__ void SplitKernel(const float *__restrict__ in, int64_t stride_r, int64_t stride_c,
+                            int rows, int cols, int cols_pad, _Float16 *__restrict__ hi,
+                            _Float16 *__restrict__ lo, int64_t ld_out) {
+  const int64_t total = (int64_t)rows * cols_pad;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int r = idx / cols_pad, c = idx % cols_pad;
+    const float v = c < cols ? in[(int64_t)r * stride_r + (int64_t)c * stride_c] : 0.0f;
+    const SplitOut s = Split(v);
+    hi[(int64_t)r * ld_out + c] = s.hi;
+    lo[(int64_t)r * ld_out + c] = s.lo;
+  }
+}
+
+}  // namespace
+
+void LaunchGemmF16(const GemmF16Args &a, hipStream_t stream) {
+  const int super_m = (a.tiles_m + 3) / 4, super_n = (a.tiles_n + 3) / 4;
+  const int nblk = super_m * super_n * 16;
+  dim3 grid(nblk), block(kThreadsF16);
+  const size_t lds = 2 * kSlabBytes;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmF16Kernel<true, false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmF16Kernel<false, false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmF16Kernel<true, true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmF16Kernel<false, true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  if (a.out_f32) {
+    if (a.relu) hipLaunchKernelGGL((GemmF16Kernel<true, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((GemmF16Kernel<false, true>), grid, block, lds, stream, a);
+  } else {
+    if (a.relu) hipLaunchKernelGGL((GemmF16Kernel<true, false>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((GemmF16Kernel<false, false>), grid, block, lds, stream, a);
+  }
+}
+
+void LaunchSplitF16(const float *in, int64_t stride_r, int64_t stride_c, int rows, int cols,
+                    int cols_pad, void *hi, void *lo, int64_t ld_out, hipStream_t stream) {
+  if (rows <= 0 || cols_pad <= 0) return;
+  int64_t n = (int64_t)rows * cols_pad;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(SplitKernel, dim3(blocks), dim3(256), 0, stream, in, stride_r, stride_c, rows,
+                     cols, cols_pad, static_cast<_Float16 *>(hi), static_cast<_Float16 *>(lo), ld_out);
+}
+
+}  // namespace pkmi

@@ -316,3 +316,72 @@ def test_model_files_roundtrip(tmp_path):
                       O.Nnet(layers).propagate(O.splice(feats, L, R)))
     with pytest.raises(pk.PkError):
         pk.AcousticModel.read(str(tmp_path / "am.prior"), str(tmp_path / "am.prior"), None, L, R, 50)
+
+
+# ------------------------------------------------------------------ f16x3 precision mode
+# Split-fp16 arithmetic on the fp16 matrix cores (include/pk_mi355.h, PK_MI355_PRECISION_F16X3):
+# not bit-exact by construction; the bar is the north_star tolerance, and the measured error
+# is asserted an order of magnitude inside it.
+
+@pytest.mark.parametrize("shape", [(1, 3, 4), (7, 440, 1024), (300, 1024, 1024), (257, 2048, 130),
+                                   (5, 513, 3000)])
+def test_f16x3_affine_close_to_fp32_chain(shape):
+    T, K, N = shape
+    rng = np.random.default_rng(T * 7 + K)
+    W = (rng.standard_normal((N, K)) * np.sqrt(2.0 / K)).astype(np.float32)
+    b = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    x = rng.standard_normal((T, K)).astype(np.float32)
+    layers = [("linear", W, b), ("relu",)]
+    gpu = pk.AcousticModel(layers, num_pdfs=N, precision="f16x3").propagate(x)
+    ref = O.Nnet(layers).propagate(x)
+    # error budget relative to the magnitude of the dot products: 2^-21 of sum |x||w|
+    scale = (np.abs(x) @ np.abs(W.T)) + np.abs(b)
+    assert np.max(np.abs(gpu - ref) / scale) < 2.0 ** -20
+
+
+def test_f16x3_full_path_S_model_within_contract():
+    layers, prior, L, R = synth.model("S")
+    wave = synth.utterance(0, seconds=3.0)
+    g = synth.global_cmvn_stats()
+    am = pk.AcousticModel(layers, prior, L, R, precision="f16x3")
+    bs = pk.BatchScorer(am, g, 1, wave.shape[0])
+    bs.set_waves([wave])
+    bs.score(0.1)
+    ref = O.Nnet(layers).am_compute(O.cmvn(g, O.Fbank().compute(wave)), prior, L, R, 0.1)
+    got = bs.fetch(0).log_prob()
+    assert_loglik_close(got, ref)                              # the 1e-4 contract
+    assert np.max(np.abs(got - ref)) < 2e-5                    # measured: ~1e-6
+    # the reference-shaped entry point runs the same arithmetic
+    d2 = pk.Decodable(am, 0.1, bs.fetch_cmvn(0))
+    assert bits_equal(d2.log_prob(), got)
+
+
+def test_f16x3_ragged_batch_and_chunking(monkeypatch):
+    layers, prior, L, R, tid2pdf = tiny_model()
+    g = synth.global_cmvn_stats()
+    lens = [16000, 399, 5000, 400, 104000, 0, 7802]
+    waves = [synth.utterance(60 + i, seconds=7.0)[:n] for i, n in enumerate(lens)]
+    am = pk.AcousticModel(layers, prior, L, R, tid2pdf, precision="f16x3")
+    nn = O.Nnet(layers)
+    outs = []
+    for chunk in ("256", "65536"):
+        monkeypatch.setenv("PK_MI355_CHUNK", chunk)
+        bs = pk.BatchScorer(am, g, len(waves), sum(lens))
+        bs.set_waves(waves)
+        bs.score(0.1)
+        outs.append([bs.fetch(u).log_prob() for u in range(len(waves))])
+    for u, w in enumerate(waves):
+        assert bits_equal(outs[0][u], outs[1][u])
+        if O.num_frames(len(w)) == 0:
+            assert outs[0][u].shape[0] == 0
+            continue
+        ref = nn.am_compute(O.cmvn(g, O.Fbank().compute(w)), prior, L, R, 0.1)
+        assert_loglik_close(outs[0][u], ref)
+
+
+def test_f16x3_rejects_unsupported_layer_patterns():
+    with pytest.raises(pk.PkError):
+        pk.AcousticModel([("linear", np.eye(8, dtype=np.float32), np.zeros(8, np.float32)), ("normalize",)],
+                         num_pdfs=8, precision="f16x3")
+    with pytest.raises(pk.PkError):
+        pk.AcousticModel([("softmax",)], num_pdfs=8, precision="f16x3")
