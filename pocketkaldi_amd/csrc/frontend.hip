@@ -9,9 +9,10 @@
 // it is taken in fp64 and rounded once, which reproduces glibc's logf except for
 // rare 1-ULP cases.
 //
-// Execution shape: one 64-lane wavefront per frame (a workgroup IS one wave), the
-// frame lives in LDS, the eight split-radix passes each run <= 64 independent
-// "L" butterflies -- one per lane -- with a wave-level barrier between passes.
+// Execution shape: one 64-lane wavefront per frame, four independent waves per
+// workgroup; frame and constant tables live in LDS, the eight split-radix passes each
+// run <= 64 independent "L" butterflies -- one per lane -- with a wave-level barrier
+// between passes.
 #include <hip/hip_runtime.h>
 
 #include "pk_kernels.h"
@@ -70,41 +71,96 @@ __device__ __forceinline__ void LButterfly(float *xr, float *xi, int base, int n
   xr[i2] = r1; xi[i2] = q1; xr[i3] = r2; xi[i3] = q2;
 }
 
-template <int LOGM>
-__device__ __forceinline__ void FftPass(float *xr, float *xi, int lane,
-                                        const FrontendTables *__restrict__ tab) {
-  constexpr int pass = kLogCplx - LOGM;
-  constexpr int q = (1 << LOGM) / 4;        // butterflies per block
-  const int first = tab->pass_start[pass];
-  const int nblk = tab->pass_start[pass + 1] - first;
-  const int b = lane / q, n = lane % q;     // q is a power of two
-  if (b < nblk) {
-    const float *tw = LOGM >= 4 ? tab->tw + tab->tw_off[LOGM] : nullptr;
-    LButterfly<LOGM>(xr, xi, tab->blk_off[first + b], n, tw);
-  }
-  __syncthreads();
+// The constant tables of the front-end, copied once per workgroup into LDS (the
+// kernel is latency-bound: a table value fetched from L2 inside every FFT pass costs
+// more than the butterfly it feeds).  Mel weights are packed back to back.
+struct LdsTables {
+  float window[kFrameLength];
+  float tw[kTwFloats];
+  float post_re[kFftCplx / 2 + 1];
+  float post_im[kFftCplx / 2 + 1];
+  float mel_w[kMelPacked];
+  short mel_off[kNumBins];
+  short mel_len[kNumBins];
+  short mel_base[kNumBins];
+  short tw_off[kLogCplx + 1];
+  short pass_start[kNumPasses + 1];
+  unsigned char blk_off[kMaxBlocks + 1];
+  unsigned char bitrev[kFftCplx];
+};
+
+// Per-wave work area: one frame.
+struct FrameLds {
+  float x[kFrameLength];       // DC-removed samples (pre-emphasis neighbour)
+  float re[kFftCplx];
+  float im[kFftCplx];
+  float pw[kFftCplx + 4];
+};
+
+// The four waves of a workgroup work on different frames and never exchange data, so
+// the barrier between FFT passes is wave-local: LDS operations of one wave complete in
+// issue order; what is needed is that they are finished and not reordered by hipcc.
+__device__ __forceinline__ void WaveSync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// A workgroup of one wave walks frames  t = blockIdx.x, blockIdx.x + gridDim.x, ...
+template <int LOGM>
+__device__ __forceinline__ void FftPass(float *xr, float *xi, int lane, const LdsTables &tab) {
+  constexpr int pass = kLogCplx - LOGM;
+  constexpr int q = (1 << LOGM) / 4;        // butterflies per block
+  const int first = tab.pass_start[pass];
+  const int nblk = tab.pass_start[pass + 1] - first;
+  const int b = lane / q, n = lane % q;     // q is a power of two
+  if (b < nblk) {
+    const float *tw = LOGM >= 4 ? tab.tw + tab.tw_off[LOGM] : nullptr;
+    LButterfly<LOGM>(xr, xi, tab.blk_off[first + b], n, tw);
+  }
+  WaveSync();
+}
+
+constexpr int kFbankWaves = 4;
+
+// Each wave of a workgroup walks frames t = blockIdx.x * 4 + wave, + gridDim.x * 4, ...
 // of utterance blockIdx.y.
 template <typename SampleT>
-__global__ __launch_bounds__(kWave) void FbankKernel(const SampleT *__restrict__ wave,
-                                                     UttLayout utts,
-                                                     const FrontendTables *__restrict__ tab,
-                                                     float *__restrict__ raw) {
-  __shared__ float s_x[kFrameLength];       // DC-removed samples (pre-emphasis neighbour)
-  __shared__ float s_re[kFftCplx];
-  __shared__ float s_im[kFftCplx];
-  __shared__ float s_pow[kFftCplx + 1];
-  __shared__ float s_sum;
+__global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
+    const SampleT *__restrict__ wave_pcm, UttLayout utts, const FrontendTables *__restrict__ gtab,
+    float *__restrict__ raw) {
+  __shared__ LdsTables tab;
+  __shared__ FrameLds frames[kFbankWaves];
 
-  const int lane = threadIdx.x;
+  // ---- tables: global -> LDS, once per workgroup
+  {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < kFrameLength; i += nt) tab.window[i] = gtab->window[i];
+    for (int i = tid; i < kTwFloats; i += nt) tab.tw[i] = gtab->tw[i];
+    for (int i = tid; i <= kFftCplx / 2; i += nt) { tab.post_re[i] = gtab->post_re[i]; tab.post_im[i] = gtab->post_im[i]; }
+    for (int i = tid; i < kMelPacked; i += nt) tab.mel_w[i] = gtab->mel_packed[i];
+    for (int i = tid; i < kNumBins; i += nt) {
+      tab.mel_off[i] = (short)gtab->mel_off[i];
+      tab.mel_len[i] = (short)gtab->mel_len[i];
+      tab.mel_base[i] = (short)gtab->mel_base[i];
+    }
+    for (int i = tid; i <= kLogCplx; i += nt) tab.tw_off[i] = (short)gtab->tw_off[i];
+    for (int i = tid; i <= kNumPasses; i += nt) tab.pass_start[i] = (short)gtab->pass_start[i];
+    for (int i = tid; i <= kMaxBlocks; i += nt) tab.blk_off[i] = (unsigned char)gtab->blk_off[i];
+    for (int i = tid; i < kFftCplx; i += nt) tab.bitrev[i] = (unsigned char)gtab->bitrev[i];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  FrameLds &fr = frames[wv];
+  float *s_x = fr.x, *s_re = fr.re, *s_im = fr.im, *s_pow = fr.pw;
   const int utt = blockIdx.y;
   const int T = utts.num_frames[utt];
-  const SampleT *w0 = wave + utts.wave_off[utt];
+  const SampleT *w0 = wave_pcm + utts.wave_off[utt];
   float *out0 = raw + utts.raw_base[utt] * kNumBins;
 
-  for (int t = blockIdx.x; t < T; t += gridDim.x) {
+  for (int t = blockIdx.x * kFbankWaves + wv; t < T; t += gridDim.x * kFbankWaves) {
     // ---- fbank.cc:74-100: the frame's 400 samples, 7 per lane (lane + 64 r)
     const SampleT *w = w0 + (int64_t)t * kFrameShift;
     float x[7];
@@ -133,15 +189,12 @@ __global__ __launch_bounds__(kWave) void FbankKernel(const SampleT *__restrict__
         int i = lane + kWave * r;
         if (i < kFrameLength) s_x[i] = x[r];
       }
-      __syncthreads();
-      if (lane == 0) {
-        float s = 0;
+      WaveSync();
+      float s = 0;
+      if (lane == 0)
         for (int i = 0; i < kFrameLength; ++i) s += s_x[i];
-        s_sum = s;
-      }
-      __syncthreads();
-      sum = s_sum;
-      __syncthreads();
+      sum = __shfl(s, 0);
+      WaveSync();
     }
     const float mean = sum / kFrameLength;
 
@@ -151,7 +204,7 @@ __global__ __launch_bounds__(kWave) void FbankKernel(const SampleT *__restrict__
       x[r] -= mean;                                   // fbank.cc:53-55
       if (i < kFrameLength) s_x[i] = x[r];
     }
-    __syncthreads();
+    WaveSync();
 
     // ---- fbank.cc:58-68: pre-emphasis in double (0.97 is a double literal), one
     // rounding to float, then the Hamming window.  De-interleave into re/im for
@@ -163,11 +216,11 @@ __global__ __launch_bounds__(kWave) void FbankKernel(const SampleT *__restrict__
       if (r < 7 && i < kFrameLength) {
         float prev = s_x[i > 0 ? i - 1 : 0];
         y = static_cast<float>(static_cast<double>(x[r]) - 0.97 * static_cast<double>(prev));
-        y *= tab->window[i];
+        y *= tab.window[i];
       }
       if (i & 1) s_im[i >> 1] = y; else s_re[i >> 1] = y;
     }
-    __syncthreads();
+    WaveSync();
 
     // ---- srfft.cc:95-237 as passes over the block schedule
     FftPass<8>(s_re, s_im, lane, tab);
@@ -178,10 +231,10 @@ __global__ __launch_bounds__(kWave) void FbankKernel(const SampleT *__restrict__
     FftPass<3>(s_re, s_im, lane, tab);
     FftPass<2>(s_re, s_im, lane, tab);
     {   // two-point blocks, srfft.cc:140-150
-      const int first = tab->pass_start[kNumPasses - 1];
-      const int nblk = tab->pass_start[kNumPasses] - first;
+      const int first = tab.pass_start[kNumPasses - 1];
+      const int nblk = tab.pass_start[kNumPasses] - first;
       for (int b = lane; b < nblk; b += kWave) {
-        int off = tab->blk_off[first + b];
+        int off = tab.blk_off[first + b];
         float tr = s_re[off] + s_re[off + 1];
         s_re[off + 1] = s_re[off] - s_re[off + 1];
         s_re[off] = tr;
@@ -190,7 +243,7 @@ __global__ __launch_bounds__(kWave) void FbankKernel(const SampleT *__restrict__
         s_im[off] = ti;
       }
     }
-    __syncthreads();
+    WaveSync();
 
     // ---- bit-reversed read (srfft.cc:239-265), real post-pass (srfft.cc:389-436)
     // and power spectrum (fbank.cc:193-211) fused: bin k and its partner 256-k.
@@ -198,10 +251,10 @@ __global__ __launch_bounds__(kWave) void FbankKernel(const SampleT *__restrict__
     for (int r = 0; r < 2; ++r) {
       const int k = 1 + lane + kWave * r;            // 1..128
       const int kd = kFftCplx - k;
-      const int jk = tab->bitrev[k], jd = tab->bitrev[kd];
+      const int jk = tab.bitrev[k], jd = tab.bitrev[kd];
       const float bk_re = s_re[jk], bk_im = s_im[jk];
       const float bd_re = s_re[jd], bd_im = s_im[jd];
-      const float kre = tab->post_re[k], kim = tab->post_im[k];
+      const float kre = tab.post_re[k], kim = tab.post_im[k];
       const float ck_re = 0.5f * (bk_re + bd_re);
       const float ck_im = 0.5f * (bk_im - bd_im);
       const float dk_re = 0.5f * (bk_im + bd_im);
@@ -223,18 +276,19 @@ __global__ __launch_bounds__(kWave) void FbankKernel(const SampleT *__restrict__
       s_pow[0] = zeroth * zeroth;
       s_pow[kFftCplx] = n2th * n2th;
     }
-    __syncthreads();
+    WaveSync();
 
     // ---- fbank.cc:165-184 (sequential float dot per bin, vector.cc:252-262),
     // floor FLT_EPSILON and log (fbank.cc:244-245)
     if (lane < kNumBins) {
-      const int off = tab->mel_off[lane], len = tab->mel_len[lane];
+      const int off = tab.mel_off[lane], len = tab.mel_len[lane];
+      const float *mw = tab.mel_w + tab.mel_base[lane];
       float e = 0.0f;
-      for (int j = 0; j < len; ++j) e += tab->mel_w[j][lane] * s_pow[off + j];
+      for (int j = 0; j < len; ++j) e += mw[j] * s_pow[off + j];
       if (e < 1.1920928955078125e-07f) e = 1.1920928955078125e-07f;
       out0[(int64_t)t * kNumBins + lane] = static_cast<float>(log(static_cast<double>(e)));
     }
-    __syncthreads();
+    WaveSync();
   }
 }
 
@@ -322,16 +376,17 @@ void LaunchFbank(const float *wave_f32, const int16_t *wave_i16, const UttLayout
                  int num_utts, int max_frames, const FrontendTables *d_tables, float *raw,
                  hipStream_t stream) {
   if (num_utts <= 0 || max_frames <= 0) return;
-  int gx = 16384 / num_utts;
+  // ~6 workgroups per CU in flight; every wave then walks several frames, which
+  // amortises the table copy
+  int gx = 1536 / num_utts;
   if (gx < 1) gx = 1;
-  if (gx > max_frames) gx = max_frames;
-  dim3 grid(gx, num_utts);
+  const int need = (max_frames + kFbankWaves - 1) / kFbankWaves;
+  if (gx > need) gx = need;
+  dim3 grid(gx, num_utts), block(kWave * kFbankWaves);
   if (wave_i16)
-    hipLaunchKernelGGL(FbankKernel<int16_t>, grid, dim3(kWave), 0, stream, wave_i16, utts,
-                       d_tables, raw);
+    hipLaunchKernelGGL(FbankKernel<int16_t>, grid, block, 0, stream, wave_i16, utts, d_tables, raw);
   else
-    hipLaunchKernelGGL(FbankKernel<float>, grid, dim3(kWave), 0, stream, wave_f32, utts,
-                       d_tables, raw);
+    hipLaunchKernelGGL(FbankKernel<float>, grid, block, 0, stream, wave_f32, utts, d_tables, raw);
 }
 
 void LaunchCmvn(const float *raw, const UttLayout &utts, int num_utts, const float *d_global41,

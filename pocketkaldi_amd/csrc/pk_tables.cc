@@ -118,6 +118,7 @@ int BuildFrontendTables(FrontendTables *t) {
   float mel_high = MelScale(kSampleRate / 2);
   float mel_delta = (mel_high - mel_low) / (kNumBins + 1);
   t->mel_maxlen = 0;
+  int packed = 0;
   for (int bin = 0; bin < kNumBins; ++bin) {
     float left = mel_low + bin * mel_delta;
     float center = mel_low + (bin + 1) * mel_delta;
@@ -140,7 +141,10 @@ int BuildFrontendTables(FrontendTables *t) {
     t->mel_off[bin] = first;
     t->mel_len[bin] = len;
     t->mel_maxlen = std::max(t->mel_maxlen, len);
-    for (int j = 0; j < len; ++j) t->mel_w[j][bin] = w[first + j];
+    if (packed + len > kMelPacked) return -5;
+    t->mel_base[bin] = packed;
+    for (int j = 0; j < len; ++j) t->mel_packed[packed + j] = w[first + j];
+    packed += len;
   }
   return 0;
 }

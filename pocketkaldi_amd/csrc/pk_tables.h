@@ -34,6 +34,7 @@ constexpr int kMaxBlocks = 171;        // 1+1+3+5+11+21+43+85 (+1 spare)
 constexpr int kTwFloats = 6 * (4 + 8 + 16 + 32 + 64);
 
 constexpr int kMelMaxLen = 64;         // longest triangle (checked at build time)
+constexpr int kMelPacked = 640;        // all triangles back to back (sum of lengths, checked)
 
 struct FrontendTables {
   float window[kFrameLength];
@@ -45,11 +46,12 @@ struct FrontendTables {
   int32_t bitrev[kFftCplx];
   float post_re[kFftCplx / 2 + 1];
   float post_im[kFftCplx / 2 + 1];
-  // mel: weights stored [j][bin] so that the 40 lanes read consecutive words
+  // mel: per bin (first FFT bin, length) and the weights of all bins back to back
   int32_t mel_off[kNumBins];
   int32_t mel_len[kNumBins];
   int32_t mel_maxlen;
-  float mel_w[kMelMaxLen][kNumBins];
+  int32_t mel_base[kNumBins];          // start of bin b's weights in mel_packed
+  float mel_packed[kMelPacked];
 };
 
 // Returns 0 on success.  Pure host code, no HIP.
