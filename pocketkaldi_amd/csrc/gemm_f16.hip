@@ -131,45 +131,65 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
     for (int y = 0; y < 2; ++y) boff[y][ks] = SwzOff(wn * 64 + 32 * y + l31, ks * 2 + kg);
   }
 
+  // ---- main loop.  A slab (BK = 32) is eight groups g = (ks, x) of six MFMAs.  The A
+  // fragments of group g+1 (and the B fragments of the second k16 step) are fetched
+  // from LDS while the MFMAs of group g issue; the barrier sits before the LAST group,
+  // when every fragment of the slab is in registers, so the DMA of slab kt+2 and the
+  // first fragments of slab kt+1 are issued under that group's MFMAs.
   const int nkt = a.K / kBKh;
   issue_slab(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (nkt > 1) issue_slab(kBKh, 1);
+  if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerWave) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
+  f16x8 ah[2], al[2];          // A fragments: current group / next group
+  f16x8 bh[2][2], bl[2][2];    // B fragments of k16 step ks: [ks][y]
+  auto read_a = [&](const unsigned char *base, int g, f16x8 &h, f16x8 &l) {
+    h = *reinterpret_cast<const f16x8 *>(base + 0 * kArrayBytes + aoff[g & 3][g >> 2]);
+    l = *reinterpret_cast<const f16x8 *>(base + 1 * kArrayBytes + aoff[g & 3][g >> 2]);
+  };
+  auto read_b = [&](const unsigned char *base, int ks) {
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      bh[ks][y] = *reinterpret_cast<const f16x8 *>(base + 2 * kArrayBytes + boff[y][ks]);
+      bl[ks][y] = *reinterpret_cast<const f16x8 *>(base + 3 * kArrayBytes + boff[y][ks]);
+    }
+  };
+  read_b(smem, 0);
+  read_a(smem, 0, ah[0], al[0]);
+
   for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) issue_slab((kt + 1) * kBKh, buf ^ 1);   // the other slab was last read in kt-1
-    const unsigned char *base = smem + buf * kSlabBytes;
+    const unsigned char *base = smem + (kt & 1) * kSlabBytes;
+    const unsigned char *next = smem + ((kt + 1) & 1) * kSlabBytes;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      f16x8 ah[4], al[4], bh[2], bl[2];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        ah[x] = *reinterpret_cast<const f16x8 *>(base + 0 * kArrayBytes + aoff[x][ks]);
-        al[x] = *reinterpret_cast<const f16x8 *>(base + 1 * kArrayBytes + aoff[x][ks]);
+    for (int g = 0; g < 8; ++g) {
+      const int ks = g >> 2, x = g & 3, cur = g & 1;
+      if (g == 7) {
+        // every fragment of this slab is in registers (or on its way: lgkmcnt(0));
+        // slab kt+1 must have landed (this wave's pieces; the barrier covers the others')
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nkt) issue_slab((kt + 2) * kBKh, kt & 1);   // nobody reads this slab any more
+        read_b(next, 0);                                         // stale on the last slab, unused
+        read_a(next, 0, ah[cur ^ 1], al[cur ^ 1]);
+      } else {
+        read_a(base, g + 1, ah[cur ^ 1], al[cur ^ 1]);
+        if (g == 2) read_b(base, 1);
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int y = 0; y < 2; ++y) {
-        bh[y] = *reinterpret_cast<const f16x8 *>(base + 2 * kArrayBytes + boff[y][ks]);
-        bl[y] = *reinterpret_cast<const f16x8 *>(base + 3 * kArrayBytes + boff[y][ks]);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[ks][y], acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[ks][y], acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[ks][y], acc[x][y], 0, 0, 0);
       }
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) {
-          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[x], bl[y], acc[x][y], 0, 0, 0);
-          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[x], bh[y], acc[x][y], 0, 0, 0);
-          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[x], bh[y], acc[x][y], 0, 0, 0);
-        }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // next slab landed (own pieces; the barrier covers the other waves'), and every
-    // wave is done reading this one before it is overwritten in kt+1
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
   }
 
   // ---- epilogue: acc[x][y][r] = D[M0 + 32x + i'][N0 + 2 l31 + y],
