@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-precision", action="store_true",
                     help="skip the supplementary run in the other precision mode")
-    ap.add_argument("--cpu-utts", type=int, default=64, help="utterances in the CPU-baseline sample (~15-20 s of CPU)")
+    ap.add_argument("--cpu-utts", type=int, default=128, help="utterances in the CPU-baseline sample (~15 s of CPU)")
     args = ap.parse_args()
 
     import torch
