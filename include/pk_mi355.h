@@ -203,6 +203,21 @@ int pk_mi355_batch_fetch(pk_mi355_batch_t *b, int utt, pk_decodable_t *out);
 int pk_mi355_batch_fetch_fbank(pk_mi355_batch_t *b, int utt, float *out);
 int pk_mi355_batch_fetch_cmvn(pk_mi355_batch_t *b, int utt, float *out);
 
+/* Device-side pk_decodable_loglikelihood (decodable.cc:24-31) for a GPU-resident consumer
+ * (decoder.cc:252-279 evaluates one (frame, transition-id) pair per arc): n pairs in
+ * device memory -> out[i] = log_prob[frame[i]][tid2pdf[trans_id[i]]] of utterance utt,
+ * on the batch's stream, nothing leaves HBM.                                       */
+int pk_mi355_batch_gather_loglik(pk_mi355_batch_t *b, int utt, const int32_t *d_frames,
+                                 const int32_t *d_trans_ids, int n, float *d_out);
+
+/* Device buffers for callers without a HIP toolchain of their own (the inputs of
+ * pk_mi355_batch_set_waves_device / pk_mi355_batch_gather_loglik).  A process must use ONE
+ * HIP runtime: allocate through these (or through the runtime this library is bound to).
+ * kind: 1 host->device, 2 device->host, 3 device->device; synchronous.              */
+void *pk_mi355_device_malloc(size_t bytes);
+void pk_mi355_device_free(void *ptr);
+int pk_mi355_memcpy(void *dst, const void *src, size_t bytes, int kind);
+
 /* The HIP stream the batch launches on (hipStream_t as void*), so callers can
  * bracket it with their own events.                                              */
 void *pk_mi355_batch_stream(pk_mi355_batch_t *b);

@@ -62,6 +62,7 @@ EXPORTS = [
     "pk_mi355_batch_score", "pk_mi355_batch_synchronize", "pk_mi355_batch_num_utts",
     "pk_mi355_batch_num_frames", "pk_mi355_batch_total_frames", "pk_mi355_batch_loglik_device",
     "pk_mi355_batch_fetch", "pk_mi355_batch_fetch_fbank", "pk_mi355_batch_fetch_cmvn",
+    "pk_mi355_batch_gather_loglik", "pk_mi355_device_malloc", "pk_mi355_device_free", "pk_mi355_memcpy",
     "pk_mi355_batch_stream", "pk_mi355_batch_enable_timing", "pk_mi355_batch_get_timing",
     "pk_mi355_am_flops_per_frame", "pk_mi355_device_count", "pk_mi355_version",
 ]
@@ -139,6 +140,12 @@ def lib():
     L.pk_mi355_batch_fetch.argtypes = [C.c_void_p, C.c_int, C.POINTER(pk_decodable_t)]
     L.pk_mi355_batch_fetch_fbank.argtypes = [C.c_void_p, C.c_int, f32p]
     L.pk_mi355_batch_fetch_cmvn.argtypes = [C.c_void_p, C.c_int, f32p]
+    L.pk_mi355_batch_gather_loglik.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.pk_mi355_device_malloc.restype = C.c_void_p
+    L.pk_mi355_device_malloc.argtypes = [C.c_size_t]
+    L.pk_mi355_device_free.restype = None
+    L.pk_mi355_device_free.argtypes = [C.c_void_p]
+    L.pk_mi355_memcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     L.pk_mi355_batch_stream.restype = C.c_void_p
     L.pk_mi355_batch_stream.argtypes = [C.c_void_p]
     L.pk_mi355_batch_enable_timing.argtypes = [C.c_void_p, C.c_int]
@@ -419,6 +426,11 @@ class BatchScorer:
         out = np.zeros((self.num_frames(utt), 40), dtype=np.float32)
         _check(lib().pk_mi355_batch_fetch_cmvn(self._h, utt, _fp(out)))
         return out
+
+    def gather_loglik(self, utt, d_frames, d_trans_ids, n, d_out):
+        """Device-side loglikelihood(frame, trans_id) for n pairs (all pointers are device pointers)."""
+        _check(lib().pk_mi355_batch_gather_loglik(self._h, utt, C.c_void_p(d_frames), C.c_void_p(d_trans_ids),
+                                                  int(n), C.c_void_p(d_out)))
 
     def enable_timing(self, on=True):
         _check(lib().pk_mi355_batch_enable_timing(self._h, 1 if on else 0))

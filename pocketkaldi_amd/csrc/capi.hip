@@ -166,6 +166,7 @@ struct pk_mi355_am {
   int input_dim = 0, output_dim = 0, feat_dim = 0;
   int max_dim_pad = 0;             // widest activation, rounded to the tile
   std::vector<int32_t> tid2pdf;
+  int32_t *d_tid2pdf = nullptr;    // device copy for the on-GPU gather
   std::vector<DevLinear> lin;      // one per linear layer, in order
   float *d_blob = nullptr;
   size_t blob_floats = 0;
@@ -544,6 +545,7 @@ void pk_mi355_am_destroy(pk_mi355_am_t *am) {
   hipSetDevice(am->device);
   FreeWorkspace(am->ws);
   hipFree(am->d_blob);
+  hipFree(am->d_tid2pdf);
   delete am;
 }
 
@@ -688,7 +690,11 @@ int pk_mi355_am_finalize(pk_mi355_am_t *am, const float *prior, int num_pdfs, in
   HIP_TRY(hipMemcpy(am->d_blob, blob.data(), sizeof(float) * off, hipMemcpyHostToDevice));
 
   am->tid2pdf.clear();
-  if (tid2pdf && num_tids > 0) am->tid2pdf.assign(tid2pdf, tid2pdf + num_tids);
+  if (tid2pdf && num_tids > 0) {
+    am->tid2pdf.assign(tid2pdf, tid2pdf + num_tids);
+    HIP_TRY(hipMalloc(&am->d_tid2pdf, sizeof(int32_t) * num_tids));
+    HIP_TRY(hipMemcpy(am->d_tid2pdf, tid2pdf, sizeof(int32_t) * num_tids, hipMemcpyHostToDevice));
+  }
   am->finalized = true;
   return 0;
 }
@@ -1135,6 +1141,37 @@ int pk_mi355_batch_fetch_cmvn(pk_mi355_batch_t *b, int utt, float *out) {
   HIP_TRY(hipStreamSynchronize(b->stream));
   for (int t = 0; t < T; ++t)
     for (int d = 0; d < kNumBins; ++d) out[(size_t)t * kNumBins + d] = tmp[(size_t)d * T + t];
+  return 0;
+}
+
+int pk_mi355_batch_gather_loglik(pk_mi355_batch_t *b, int utt, const int32_t *d_frames,
+                                 const int32_t *d_trans_ids, int n, float *d_out) {
+  if (!b || utt < 0 || utt >= b->num_utts || !d_frames || !d_trans_ids || !d_out)
+    return Fail(PK_MI355_E_INVALID, "bad gather arguments");
+  if (!b->scored) return Fail(PK_MI355_E_STATE, "batch not scored");
+  int rc = UseDevice(b->device);
+  if (rc) return rc;
+  LaunchGather(pk_mi355_batch_loglik_device(b, utt), b->am->num_pdfs, b->am->d_tid2pdf,
+               (int)b->am->tid2pdf.size(), d_frames, d_trans_ids, n, d_out, b->stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return Fail(PK_MI355_E_DEVICE, "gather: %s", hipGetErrorString(e));
+  return 0;
+}
+
+void *pk_mi355_device_malloc(size_t bytes) {
+  if (UseDevice(g_device)) return nullptr;
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) { Fail(PK_MI355_E_DEVICE, "hipMalloc: %s", hipGetErrorString(e)); return nullptr; }
+  return p;
+}
+
+void pk_mi355_device_free(void *p) { hipFree(p); }
+
+int pk_mi355_memcpy(void *dst, const void *src, size_t bytes, int kind) {
+  hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  if (kind < 1 || kind > 3) return Fail(PK_MI355_E_INVALID, "memcpy kind must be 1 (H2D), 2 (D2H) or 3 (D2D)");
+  HIP_TRY(hipMemcpy(dst, src, bytes, k));
   return 0;
 }
 

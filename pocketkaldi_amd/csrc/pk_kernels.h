@@ -120,6 +120,10 @@ enum TailMode {
 void LaunchTail(int mode, const float *in, int64_t ld_in, int rows, int n, const float *log_prior,
                 float scale, float *out, int64_t ld_out, hipStream_t stream);
 
+// Device-side pk_decodable_loglikelihood (decodable.cc:24-31) for n (frame, trans_id) pairs.
+void LaunchGather(const float *ll, int64_t ld, const int32_t *tid2pdf, int num_tids,
+                  const int32_t *frames, const int32_t *tids, int n, float *out, hipStream_t stream);
+
 }  // namespace pkmi
 
 #endif  // PK_KERNELS_H_

@@ -164,7 +164,28 @@ __global__ __launch_bounds__(kTailThreads) void TailKernel(const float *__restri
   }
 }
 
+// decodable.cc:24-31 for many (frame, transition-id) pairs at once, device side:
+// out[i] = ll[frame[i]][tid2pdf[tid[i]]]
+__global__ void GatherKernel(const float *__restrict__ ll, int64_t ld, const int32_t *__restrict__ tid2pdf,
+                             int num_tids, const int32_t *__restrict__ frames,
+                             const int32_t *__restrict__ tids, int n, float *__restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int tid = tids[i];
+    const int pdf = tid2pdf ? tid2pdf[tid < num_tids ? tid : 0] : tid;
+    out[i] = ll[(int64_t)frames[i] * ld + pdf];
+  }
+}
+
 }  // namespace
+
+void LaunchGather(const float *ll, int64_t ld, const int32_t *tid2pdf, int num_tids,
+                  const int32_t *frames, const int32_t *tids, int n, float *out, hipStream_t stream) {
+  if (n <= 0) return;
+  int blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(GatherKernel, dim3(blocks), dim3(256), 0, stream, ll, ld, tid2pdf, num_tids, frames,
+                     tids, n, out);
+}
 
 void LaunchRelu(float *x, int64_t n, hipStream_t stream) {
   if (n <= 0) return;

@@ -385,3 +385,38 @@ def test_f16x3_rejects_unsupported_layer_patterns():
                          num_pdfs=8, precision="f16x3")
     with pytest.raises(pk.PkError):
         pk.AcousticModel([("softmax",)], num_pdfs=8, precision="f16x3")
+
+
+def test_device_side_loglikelihood_gather():
+    """decodable.cc:24-31 for many (frame, trans_id) pairs without leaving HBM."""
+    import ctypes
+    L_ = pk.lib()
+
+    def to_device(arr):
+        p = L_.pk_mi355_device_malloc(arr.nbytes)
+        assert p
+        assert L_.pk_mi355_memcpy(p, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes, 1) == 0   # H2D
+        return p
+
+    layers, prior, L, R, tid2pdf = tiny_model()
+    g = synth.global_cmvn_stats()
+    waves = [synth.utterance(80, 2.0), synth.utterance(81, 1.0)]
+    am = pk.AcousticModel(layers, prior, L, R, tid2pdf)
+    bs = pk.BatchScorer(am, g, 2, sum(len(w) for w in waves))
+    bs.set_waves(waves)
+    bs.score(0.1)
+    for u in range(2):
+        d = bs.fetch(u)
+        T = bs.num_frames(u)
+        rng = np.random.default_rng(u)
+        frames = rng.integers(0, T, 1000).astype(np.int32)
+        tids = rng.integers(1, len(tid2pdf), 1000).astype(np.int32)
+        out = np.zeros(1000, dtype=np.float32)
+        df, dt, do = to_device(frames), to_device(tids), to_device(out)
+        bs.gather_loglik(u, df, dt, 1000, do)
+        bs.synchronize()
+        assert L_.pk_mi355_memcpy(out.ctypes.data_as(ctypes.c_void_p), do, out.nbytes, 2) == 0   # D2H
+        want = np.array([d.loglikelihood(int(f), int(t)) for f, t in zip(frames, tids)], dtype=np.float32)
+        assert bits_equal(out, want)
+        for p in (df, dt, do):
+            L_.pk_mi355_device_free(p)
