@@ -151,8 +151,8 @@ struct HostLayer {
 
 struct DevLinear {
   int K = 0, N = 0, Kpad = 0, Npad = 0;
-  size_t wt_off = 0, b_off = 0;    // float offsets into the blob
-  size_t wl_off = 0;               // f16x3 mode: wt_off = W hi, wl_off = W lo ([Npad][Kpad] halves)
+  size_t wt_off = 0, b_off = 0;    // float offsets into the blob (f16x3: wt_off = interleaved
+                                   // (hi, lo) rows [Npad][2 Kpad] halves)
 };
 
 struct Workspace;   // forward
@@ -184,27 +184,23 @@ struct ExecBufs {
   float *b = nullptr;     // pong
   int64_t rows_cap = 0;
   int64_t in_floats = 0, act_floats = 0;
-  // f16x3 mode: (hi, lo) activation pairs [rows_cap][max Npad], ping/pong; the plain
-  // input pair [rows_cap][Kpad0]; `a` holds the fp32 logits, `b` softmax probabilities
-  _Float16 *h[2] = {nullptr, nullptr}, *l[2] = {nullptr, nullptr};
-  _Float16 *xin_h = nullptr, *xin_l = nullptr;
+  // f16x3 mode: interleaved (hi, lo) activation rows [rows_cap][2 max Npad], ping/pong; the
+  // plain input rows [rows_cap][2 Kpad0]; `a` holds the fp32 logits, `b` softmax probabilities
+  _Float16 *h[2] = {nullptr, nullptr};
+  _Float16 *xin = nullptr;
 };
 
 int AllocExec(const pk_mi355_am *am, int64_t rows_cap, ExecBufs *e) {
   e->rows_cap = rows_cap;
   if (am->precision == PK_MI355_PRECISION_F16X3) {
-    const size_t act = sizeof(_Float16) * (size_t)am->max_dim_pad * rows_cap;
-    const size_t xin = sizeof(_Float16) * (size_t)RoundUp(am->input_dim, kBKF16) * (rows_cap + 16);
+    const size_t act = sizeof(_Float16) * 2 * (size_t)am->max_dim_pad * rows_cap;
+    const size_t xin = sizeof(_Float16) * 2 * (size_t)RoundUp(am->input_dim, kBKF16) * (rows_cap + 16);
     for (int i = 0; i < 2; ++i) {
       HIP_TRY(hipMalloc(&e->h[i], act));
-      HIP_TRY(hipMalloc(&e->l[i], act));
       HIP_TRY(hipMemset(e->h[i], 0, act));
-      HIP_TRY(hipMemset(e->l[i], 0, act));
     }
-    HIP_TRY(hipMalloc(&e->xin_h, xin));
-    HIP_TRY(hipMalloc(&e->xin_l, xin));
-    HIP_TRY(hipMemset(e->xin_h, 0, xin));
-    HIP_TRY(hipMemset(e->xin_l, 0, xin));
+    HIP_TRY(hipMalloc(&e->xin, xin));
+    HIP_TRY(hipMemset(e->xin, 0, xin));
   }
   e->act_floats = (int64_t)am->max_dim_pad * rows_cap;
   e->in_floats = RoundUp(am->input_dim, kBK) * rows_cap;
@@ -221,9 +217,8 @@ void FreeExec(ExecBufs *e) {
   hipFree(e->a);
   hipFree(e->b);
   hipFree(e->in);
-  for (int i = 0; i < 2; ++i) { hipFree(e->h[i]); hipFree(e->l[i]); }
-  hipFree(e->xin_h);
-  hipFree(e->xin_l);
+  for (int i = 0; i < 2; ++i) hipFree(e->h[i]);
+  hipFree(e->xin);
   *e = ExecBufs();
 }
 
@@ -373,11 +368,11 @@ int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t
 }
 
 // f16x3 mode: the same layer walk on (hi, lo) fp16 pairs, everything frame-major.
-// Input: xh/xl [rows][ldx] (ldx = feat_dim for the spliced view of the CMVN output,
-// row r = frames r .. r+L+R, am.cc:65-88; or the padded plain input).  Finalize has
+// Input: interleaved rows x [rows][ldx halves] (ldx = 2 feat_dim for the spliced view of
+// the CMVN output, row r = frames r .. r+L+R, am.cc:65-88; or the padded plain input).  Finalize has
 // already checked the layer pattern: (Linear [ReLU])+ [Softmax].
-int RunLayersF16(const pk_mi355_am *am, const ExecBufs &e, const _Float16 *xh, const _Float16 *xl,
-                 int64_t ldx, int rows, bool want_tail, float scale, float *tail_out,
+int RunLayersF16(const pk_mi355_am *am, const ExecBufs &e, const _Float16 *x, int64_t ldx, int rows,
+                 bool want_tail, float scale, float *tail_out,
                  int64_t tail_ld, hipStream_t stream, Timer *timer, ExecResult *res) {
   const int rows_pad = (int)RoundUp(rows, kTileF16);
   if (rows_pad > e.rows_cap) return Fail(PK_MI355_E_INVALID, "chunk larger than workspace");
@@ -391,24 +386,22 @@ int RunLayersF16(const pk_mi355_am *am, const ExecBufs &e, const _Float16 *xh, c
     const DevLinear &D = am->lin[li];
     const bool last = (li == nlin - 1);
     GemmF16Args g;
-    g.Xh = xh; g.Xl = xl; g.ldx = ldx;
-    g.Wh = reinterpret_cast<const _Float16 *>(blob + D.wt_off);
-    g.Wl = reinterpret_cast<const _Float16 *>(blob + D.wl_off);
-    g.ldw = D.Kpad;
+    g.X = x; g.ldx = ldx;
+    g.W = reinterpret_cast<const _Float16 *>(blob + D.wt_off);
+    g.ldw = 2 * D.Kpad;
     g.K = D.Kpad;
     g.bias = blob + D.b_off;
     g.relu = (i + 1 < nl && am->layers[i + 1].type == PK_NNET_RELU_LAYER) ? 1 : 0;
     g.out_f32 = last ? e.a : nullptr;
-    g.out_hi = last ? nullptr : e.h[buf];
-    g.out_lo = last ? nullptr : e.l[buf];
-    g.ldo = D.Npad;
+    g.out = last ? nullptr : e.h[buf];
+    g.ldo = last ? D.Npad : 2 * D.Npad;
     g.tiles_m = rows_pad / kTileF16;
     g.tiles_n = D.Npad / kTileF16;
     {
       Scoped t(timer, PK_MI355_K_GEMM, stream);
       LaunchGemmF16(g, stream);
     }
-    xh = e.h[buf]; xl = e.l[buf]; ldx = D.Npad;
+    x = e.h[buf]; ldx = 2 * D.Npad;
     out_ld = D.Npad;
     buf ^= 1;
     ++li;
@@ -438,7 +431,7 @@ struct Workspace {
   ExecBufs exec;
   float *d_feats = nullptr;  int64_t feats_cap = 0;     // frame-major host upload
   float *d_yt = nullptr;     int64_t yt_ld = 0;          // [feat_dim][yt_ld]
-  _Float16 *d_yh = nullptr, *d_yl = nullptr;            // f16x3: [yt_ld][feat_dim] (hi, lo)
+  _Float16 *d_y2 = nullptr;                             // f16x3: interleaved rows [yt_ld][2 feat_dim]
   float *d_out = nullptr;    int64_t out_cap = 0;        // [rows][num_pdfs]
   hipStream_t stream = nullptr;
 };
@@ -469,10 +462,8 @@ int EnsureWorkspace(pk_mi355_am *am, int64_t frames, int width) {
     HIP_TRY(hipMalloc(&w->d_yt, sizeof(float) * w->yt_ld * am->feat_dim));
     HIP_TRY(hipMemset(w->d_yt, 0, sizeof(float) * w->yt_ld * am->feat_dim));
     if (am->precision == PK_MI355_PRECISION_F16X3) {
-      hipFree(w->d_yh);
-      hipFree(w->d_yl);
-      HIP_TRY(hipMalloc(&w->d_yh, sizeof(_Float16) * w->yt_ld * am->feat_dim));
-      HIP_TRY(hipMalloc(&w->d_yl, sizeof(_Float16) * w->yt_ld * am->feat_dim));
+      hipFree(w->d_y2);
+      HIP_TRY(hipMalloc(&w->d_y2, sizeof(_Float16) * 2 * w->yt_ld * am->feat_dim));
     }
   }
   const int64_t need_out = frames * std::max(am->output_dim, 1);
@@ -489,8 +480,7 @@ void FreeWorkspace(Workspace *w) {
   FreeExec(&w->exec);
   hipFree(w->d_feats);
   hipFree(w->d_yt);
-  hipFree(w->d_yh);
-  hipFree(w->d_yl);
+  hipFree(w->d_y2);
   hipFree(w->d_out);
   if (w->stream) hipStreamDestroy(w->stream);
   delete w;
@@ -622,9 +612,7 @@ int pk_mi355_am_finalize(pk_mi355_am_t *am, const float *prior, int num_pdfs, in
     if (f16) {
       D.Kpad = (int)RoundUp(D.K, kBKF16);
       D.Npad = (int)RoundUp(D.N, kTileF16);
-      const size_t wfloats = (size_t)D.Kpad * D.Npad / 2;     // halves -> float units
-      D.wt_off = off; off += wfloats;
-      D.wl_off = off; off += wfloats;
+      D.wt_off = off; off += (size_t)D.Kpad * D.Npad;         // 2 Kpad halves per row = Kpad floats
     } else {
       D.Kpad = (int)RoundUp(D.K, kBK);
       D.Npad = (int)RoundUp(D.N, kTile);
@@ -666,16 +654,17 @@ int pk_mi355_am_finalize(pk_mi355_am_t *am, const float *prior, int num_pdfs, in
     if (L.type != PK_NNET_LINEAR_LAYER) continue;
     const DevLinear &D = am->lin[li++];
     if (f16) {
-      // W stays [out][in] (k contiguous), split into fp16 hi / lo = fp16(w - hi)
-      _Float16 *wh = reinterpret_cast<_Float16 *>(blob.data() + D.wt_off);
-      _Float16 *wl = reinterpret_cast<_Float16 *>(blob.data() + D.wl_off);
+      // W stays [out][in] (k contiguous), split into fp16 hi and lo = fp16(w - hi), the
+      // pairs interleaved in chunks of 8 k's (see gemm_f16.hip)
+      _Float16 *w2 = reinterpret_cast<_Float16 *>(blob.data() + D.wt_off);
       for (int o = 0; o < D.N; ++o)
         for (int k = 0; k < D.K; ++k) {
           float v = L.W[(size_t)o * D.K + k];
           v = std::min(std::max(v, -65504.0f), 65504.0f);
           const _Float16 hi = static_cast<_Float16>(v);
-          wh[(size_t)o * D.Kpad + k] = hi;
-          wl[(size_t)o * D.Kpad + k] = static_cast<_Float16>(v - static_cast<float>(hi));
+          _Float16 *dst = w2 + (size_t)o * 2 * D.Kpad + (k >> 3) * 16 + (k & 7);
+          dst[0] = hi;
+          dst[8] = static_cast<_Float16>(v - static_cast<float>(hi));
         }
     } else {
       float *wt = blob.data() + D.wt_off;
@@ -775,9 +764,8 @@ int pk_mi355_nnet_propagate(pk_mi355_am_t *am, const pk_matrix_t *in, pk_matrix_
     ExecResult res;
     if (am->precision == PK_MI355_PRECISION_F16X3) {
       const int kp = (int)RoundUp(D, kBKF16);
-      LaunchSplitF16(w->d_feats + r0 * D, D, 1, rows, D, kp, w->exec.xin_h, w->exec.xin_l, kp, w->stream);
-      rc = RunLayersF16(am, w->exec, w->exec.xin_h, w->exec.xin_l, kp, rows, false, 1.0f, nullptr, 0,
-                        w->stream, nullptr, &res);
+      LaunchSplitF16(w->d_feats + r0 * D, D, 1, rows, D, kp, w->exec.xin, 2 * kp, w->stream);
+      rc = RunLayersF16(am, w->exec, w->exec.xin, 2 * kp, rows, false, 1.0f, nullptr, 0, w->stream, nullptr, &res);
     } else {
       LaunchTransposeToCols(w->d_feats + r0 * D, D, rows, D, w->exec.in, w->exec.rows_cap, w->stream);
       rc = RunLayers(am, w->exec, nullptr, 0, 0, rows, false, 1.0f, nullptr, 0, w->stream, nullptr, &res);
@@ -814,10 +802,10 @@ void pk_decodable_init(pk_decodable_t *self, pk_mi355_am_t *am, float prob_scale
   if (e != hipSuccess) { dev_fail(e); return; }
   LaunchPadTranspose(w->d_feats, T, D, am->left, am->right, w->d_yt, w->yt_ld, 0, w->stream);
   const bool f16 = am->precision == PK_MI355_PRECISION_F16X3;
-  if (f16) LaunchSplitF16(w->d_yt, 1, w->yt_ld, (int)w->yt_ld, D, D, w->d_yh, w->d_yl, D, w->stream);
+  if (f16) LaunchSplitF16(w->d_yt, 1, w->yt_ld, (int)w->yt_ld, D, D, w->d_y2, 2 * D, w->stream);
   for (int64_t r0 = 0; r0 < T; r0 += kSingleChunk) {
     const int rows = (int)std::min<int64_t>(kSingleChunk, T - r0);
-    const int rc = f16 ? RunLayersF16(am, w->exec, w->d_yh + r0 * D, w->d_yl + r0 * D, D, rows, true, prob_scale,
+    const int rc = f16 ? RunLayersF16(am, w->exec, w->d_y2 + r0 * 2 * D, 2 * D, rows, true, prob_scale,
                                       w->d_out + r0 * N, N, w->stream, nullptr, nullptr)
                        : RunLayers(am, w->exec, w->d_yt + r0, w->yt_ld, D, rows, true, prob_scale,
                                    w->d_out + r0 * N, N, w->stream, nullptr, nullptr);
@@ -881,7 +869,7 @@ struct pk_mi355_batch {
   // stages
   float *d_raw = nullptr;   // [max_frames][40]
   float *d_yt = nullptr;    // [feat_dim][ldy]
-  _Float16 *d_yh = nullptr, *d_yl = nullptr;   // f16x3: [ldy][feat_dim] (hi, lo)
+  _Float16 *d_y2 = nullptr;   // f16x3: interleaved (hi, lo) rows [ldy][2 feat_dim]
   int64_t ldy = 0;
   float *d_ll = nullptr;    // [max_cols][num_pdfs]
   ExecBufs exec;
@@ -977,8 +965,7 @@ pk_mi355_batch_t *pk_mi355_batch_create(pk_mi355_am_t *am, const float *global_s
   chk(hipMalloc(&b->d_yt, sizeof(float) * b->ldy * kNumBins));
   if (ok) chk(hipMemset(b->d_yt, 0, sizeof(float) * b->ldy * kNumBins));
   if (am->precision == PK_MI355_PRECISION_F16X3) {
-    chk(hipMalloc(&b->d_yh, sizeof(_Float16) * b->ldy * kNumBins));
-    chk(hipMalloc(&b->d_yl, sizeof(_Float16) * b->ldy * kNumBins));
+    chk(hipMalloc(&b->d_y2, sizeof(_Float16) * 2 * b->ldy * kNumBins));
   }
   chk(hipMalloc(&b->d_ll, sizeof(float) * b->max_cols * am->num_pdfs));
   if (ok && AllocExec(am, b->chunk, &b->exec)) ok = false;
@@ -994,7 +981,7 @@ void pk_mi355_batch_destroy(pk_mi355_batch_t *b) {
   hipFree(b->d_tables); hipFree(b->d_global); hipFree(b->d_cmvn_tab);
   hipFree(b->d_wave); hipFree(b->d_wave_i16);
   hipFree(b->d_wave_off); hipFree(b->d_raw_base); hipFree(b->d_pad_base); hipFree(b->d_T);
-  hipFree(b->d_raw); hipFree(b->d_yt); hipFree(b->d_yh); hipFree(b->d_yl); hipFree(b->d_ll);
+  hipFree(b->d_raw); hipFree(b->d_yt); hipFree(b->d_y2); hipFree(b->d_ll);
   if (b->stream) hipStreamDestroy(b->stream);
   delete b;
 }
@@ -1068,11 +1055,11 @@ int pk_mi355_batch_score(pk_mi355_batch_t *b, float prob_scale, int sync) {
   const bool f16 = am->precision == PK_MI355_PRECISION_F16X3;
   if (f16) {
     Scoped t(tm, PK_MI355_K_OTHER, b->stream);
-    LaunchSplitF16(b->d_yt, 1, b->ldy, (int)b->ldy, kNumBins, kNumBins, b->d_yh, b->d_yl, kNumBins, b->stream);
+    LaunchSplitF16(b->d_yt, 1, b->ldy, (int)b->ldy, kNumBins, kNumBins, b->d_y2, 2 * kNumBins, b->stream);
   }
   for (int64_t c0 = 0; c0 < b->total_cols; c0 += b->chunk) {
     const int rows = (int)std::min<int64_t>(b->chunk, b->total_cols - c0);
-    rc = f16 ? RunLayersF16(am, b->exec, b->d_yh + c0 * kNumBins, b->d_yl + c0 * kNumBins, kNumBins, rows, true,
+    rc = f16 ? RunLayersF16(am, b->exec, b->d_y2 + c0 * 2 * kNumBins, 2 * kNumBins, rows, true,
                             prob_scale, b->d_ll + c0 * N, N, b->stream, tm, nullptr)
              : RunLayers(am, b->exec, b->d_yt + c0, b->ldy, kNumBins, rows, true, prob_scale,
                          b->d_ll + c0 * N, N, b->stream, tm, nullptr);

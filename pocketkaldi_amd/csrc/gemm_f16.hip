@@ -12,17 +12,21 @@
 // relative on log-likelihoods -- inside the 1e-4 contract, not bit-exact.  Range: fp16
 // saturates at 65504; the split clamps instead of overflowing.
 //
-// Layout (everything frame-major here): X = [rows][K] fp16 hi / lo (rows = frames, k
-// contiguous), W = [N][K] fp16 hi / lo -- the model file's own [out][in] order -- and
-// D = [rows][N].  Layer 1 reads the CMVN output [frames][40] with row stride 40 and
-// K = 440: the splice (am.cc:65-88) is again just an address function.
+// Layout (everything frame-major here): X = [rows][K] (rows = frames, k contiguous),
+// W = [N][K] -- the model file's own [out][in] order -- D = [rows][N].  A row stores its
+// (hi, lo) pairs interleaved in chunks of 8 k's: [hi k0..7][lo k0..7][hi k8..15][lo ...],
+// so the 64 bytes one k16 step needs of a row are contiguous.  Layer 1 reads the CMVN
+// output [frames][40] (5 chunks per frame, row stride 80 halves) with K = 440: the
+// splice (am.cc:65-88) is again just an address function.
 //
 // Tile 256 x 256 per 512-thread workgroup (8 waves as 2 x 4, 128 x 64 per wave = 4 x 2
-// MFMA tiles, 128 accumulator registers), BK = 32, two 64 KiB LDS slabs, LDS-DMA
-// staging with the XOR swizzle on the SOURCE address (linear LDS destination) and the
-// same XOR on the ds_read_b128 fragment reads (conflict-free).  The two column
-// sub-tiles of a wave take interleaved columns so that an output row is written as
-// packed pairs (128 contiguous bytes of fp16, 256 of fp32 per store).
+// MFMA tiles, 128 accumulator registers).  The k loop advances in k16 "half-slabs" of
+// 32 KiB (256 X rows + 256 W rows x 64 bytes) through a ring of FOUR LDS buffers filled
+// by LDS-DMA three half-slabs ahead (the DMA wait + barrier was where the waves sat:
+// 33 % of their lifetime with a one-slab lead).  XOR swizzle on the DMA SOURCE address
+// (linear LDS destination) and on the ds_read_b128 fragment reads (conflict-free).  The
+// two column sub-tiles of a wave take interleaved columns so that an output row is
+// written as packed pairs.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
@@ -41,11 +45,12 @@ typedef const __attribute__((address_space(1))) void *GlobalPtr;
 typedef __attribute__((address_space(3))) void *LdsPtr;
 
 constexpr int kT = kTileF16;                  // 256: tile edge
-constexpr int kBKh = 32;                      // k per slab (halves): 64-byte LDS rows
+constexpr int kStepK = 16;                    // k per half-slab = one MFMA k16 step
 constexpr int kThreadsF16 = 512;
-constexpr int kArrayBytes = kT * kBKh * 2;    // one operand array of one slab: 16 KiB
-constexpr int kSlabBytes = 4 * kArrayBytes;   // X hi, X lo, W hi, W lo: 64 KiB
-constexpr int kPiecesPerWave = 8;             // 64 x 1 KiB pieces per slab / 8 waves
+constexpr int kOperandBytes = kT * 64;        // one operand of one half-slab: 256 rows x 64 B
+constexpr int kHalfSlabBytes = 2 * kOperandBytes;   // X rows, then W rows: 32 KiB
+constexpr int kRingF16 = 4;
+constexpr int kPiecesPerWave = 4;             // 32 x 1 KiB pieces per half-slab / 8 waves
 
 // LDS row (0..255) of the W tile -> column n of the tile.  Within each block of 64
 // columns sub-tile y of a wave owns columns 2 i' + y, stored as 32 consecutive LDS rows.
@@ -53,9 +58,10 @@ __device__ __forceinline__ int WRowToCol(int row) {
   return (row & ~63) + 2 * (row & 31) + ((row >> 5) & 1);
 }
 
-// byte offset of logical 16-byte chunk c (4 per 64-byte row) of LDS row `row`
-__device__ __forceinline__ int SwzOff(int row, int c) {
-  return row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+// byte offset of logical 16-byte position q of LDS row `row`; the four positions of a
+// 64-byte row are [k0..7 hi][k0..7 lo][k8..15 hi][k8..15 lo]
+__device__ __forceinline__ int SwzOff(int row, int q) {
+  return row * 64 + ((q ^ ((row >> 2) & 3)) << 4);
 }
 
 struct SplitOut {
@@ -90,27 +96,23 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
   const int wm = wave >> 2, wn = wave & 3;          // 2 x 4 waves
   const int l31 = lane & 31, kg = lane >> 5;
 
-  // ---- DMA role of this lane: pieces 2 wave, 2 wave + 1 of each of the four arrays;
-  // a piece is 16 LDS rows, lane -> row (lane >> 2), stored chunk (lane & 3)
-  const _Float16 *src[2][4];
+  // ---- DMA role of this lane: pieces 2 wave, 2 wave + 1 of X and of W; a piece is 16
+  // LDS rows, lane -> row (lane >> 2), stored position (lane & 3)
+  const _Float16 *src[2][2];
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     const int row = (wave * 2 + p) * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ ((row >> 2) & 3);    // logical chunk landing at this lane's slot
-    const int64_t xoff = (int64_t)(m0 + row) * a.ldx + c * 8;
-    const int64_t woff = (int64_t)(n0 + WRowToCol(row)) * a.ldw + c * 8;
-    src[p][0] = a.Xh + xoff;
-    src[p][1] = a.Xl + xoff;
-    src[p][2] = a.Wh + woff;
-    src[p][3] = a.Wl + woff;
+    const int q = (lane & 3) ^ ((row >> 2) & 3);    // logical position landing at this lane's slot
+    src[p][0] = a.X + (int64_t)(m0 + row) * a.ldx + q * 8;
+    src[p][1] = a.W + (int64_t)(n0 + WRowToCol(row)) * a.ldw + q * 8;
   }
-  auto issue_slab = [&](int k0, int buf) {
+  auto issue_step = [&](int h, int slot) {          // k16 step h: 32 halves of every row
 #pragma unroll
-    for (int arr = 0; arr < 4; ++arr)
+    for (int op = 0; op < 2; ++op)
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
-        unsigned char *dst = smem + buf * kSlabBytes + arr * kArrayBytes + (wave * 2 + p) * 1024;
-        __builtin_amdgcn_global_load_lds((GlobalPtr)(src[p][arr] + k0), (LdsPtr)dst, 16, 0, 0);
+        unsigned char *dst = smem + slot * kHalfSlabBytes + op * kOperandBytes + (wave * 2 + p) * 1024;
+        __builtin_amdgcn_global_load_lds((GlobalPtr)(src[p][op] + h * 32), (LdsPtr)dst, 16, 0, 0);
       }
   };
 
@@ -120,82 +122,98 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
 #pragma unroll
     for (int y = 0; y < 2; ++y) acc[x][y] = f32x16{0};
 
-  // fragment byte offsets inside one operand array, per k16 step ks (0, 1):
-  // A sub-tile x: LDS row wm*128 + 32x + l31; B sub-tile y: LDS row wn*64 + 32y + l31
-  int aoff[4][2], boff[2][2];
+  // fragment byte offsets inside a half-slab: A sub-tile x = LDS row wm*128 + 32x + l31 of
+  // the X rows, B sub-tile y = LDS row wn*64 + 32y + l31 of the W rows; hi at logical
+  // position 2 kg, lo at 2 kg + 1
+  int aoff_h[4], aoff_l[4], boff_h[2], boff_l[2];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
+  for (int x = 0; x < 4; ++x) {
+    aoff_h[x] = SwzOff(wm * 128 + 32 * x + l31, 2 * kg);
+    aoff_l[x] = SwzOff(wm * 128 + 32 * x + l31, 2 * kg + 1);
+  }
 #pragma unroll
-    for (int x = 0; x < 4; ++x) aoff[x][ks] = SwzOff(wm * 128 + 32 * x + l31, ks * 2 + kg);
-#pragma unroll
-    for (int y = 0; y < 2; ++y) boff[y][ks] = SwzOff(wn * 64 + 32 * y + l31, ks * 2 + kg);
+  for (int y = 0; y < 2; ++y) {
+    boff_h[y] = kOperandBytes + SwzOff(wn * 64 + 32 * y + l31, 2 * kg);
+    boff_l[y] = kOperandBytes + SwzOff(wn * 64 + 32 * y + l31, 2 * kg + 1);
   }
 
-  // ---- main loop.  A slab (BK = 32) is eight groups g = (ks, x) of six MFMAs.  The A
-  // fragments of group g+1 (and the B fragments of the second k16 step) are fetched
-  // from LDS while the MFMAs of group g issue; the barrier sits before the LAST group,
-  // when every fragment of the slab is in registers, so the DMA of slab kt+2 and the
-  // first fragments of slab kt+1 are issued under that group's MFMAs.
-  const int nkt = a.K / kBKh;
-  issue_slab(0, 0);
-  if (nkt > 1) issue_slab(kBKh, 1);
-  if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerWave) : "memory");
+  // ---- main loop over k16 steps h.  Ring of four half-slabs, DMA three steps ahead.  A
+  // step is four groups (x = 0..3) of six MFMAs; the A fragments of the next group are
+  // fetched while the current group's MFMAs issue.  Before the LAST group of step h:
+  // every fragment of step h is in registers (lgkmcnt(0)), this wave's pieces of step
+  // h+1 have landed (counted vmcnt), barrier; then the DMA of step h+4 goes into step h's
+  // buffer and the first fragments of step h+1 are read, all under the last group's MFMAs.
+  const int nsteps = a.K / kStepK;
+  issue_step(0, 0);
+  if (nsteps > 1) issue_step(1, 1);
+  if (nsteps > 2) issue_step(2, 2);
+  if (nsteps > 3) issue_step(3, 3);
+  if (nsteps > 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * kPiecesPerWave) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
   f16x8 ah[2], al[2];          // A fragments: current group / next group
-  f16x8 bh[2][2], bl[2][2];    // B fragments of k16 step ks: [ks][y]
-  auto read_a = [&](const unsigned char *base, int g, f16x8 &h, f16x8 &l) {
-    h = *reinterpret_cast<const f16x8 *>(base + 0 * kArrayBytes + aoff[g & 3][g >> 2]);
-    l = *reinterpret_cast<const f16x8 *>(base + 1 * kArrayBytes + aoff[g & 3][g >> 2]);
+  f16x8 bh[2][2], bl[2][2];    // B fragments of the current / next step: [parity][y]
+  auto read_a = [&](const unsigned char *base, int x, f16x8 &h, f16x8 &l) {
+    h = *reinterpret_cast<const f16x8 *>(base + aoff_h[x]);
+    l = *reinterpret_cast<const f16x8 *>(base + aoff_l[x]);
   };
-  auto read_b = [&](const unsigned char *base, int ks) {
+  auto read_b = [&](const unsigned char *base, int par) {
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
-      bh[ks][y] = *reinterpret_cast<const f16x8 *>(base + 2 * kArrayBytes + boff[y][ks]);
-      bl[ks][y] = *reinterpret_cast<const f16x8 *>(base + 3 * kArrayBytes + boff[y][ks]);
+      bh[par][y] = *reinterpret_cast<const f16x8 *>(base + boff_h[y]);
+      bl[par][y] = *reinterpret_cast<const f16x8 *>(base + boff_l[y]);
     }
   };
   read_b(smem, 0);
   read_a(smem, 0, ah[0], al[0]);
 
-  for (int kt = 0; kt < nkt; ++kt) {
-    const unsigned char *base = smem + (kt & 1) * kSlabBytes;
-    const unsigned char *next = smem + ((kt + 1) & 1) * kSlabBytes;
+  auto step = [&](int h, const int par) {             // par = h & 1, compile-time in the body
+    const int slot = h & (kRingF16 - 1);
+    const unsigned char *base = smem + slot * kHalfSlabBytes;
+    const unsigned char *next = smem + ((h + 1) & (kRingF16 - 1)) * kHalfSlabBytes;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const int ks = g >> 2, x = g & 3, cur = g & 1;
-      if (g == 7) {
-        // every fragment of this slab is in registers (or on its way: lgkmcnt(0));
-        // slab kt+1 must have landed (this wave's pieces; the barrier covers the others')
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int x = 0; x < 4; ++x) {
+      const int cur = x & 1;
+      if (x == 3) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0): all of step h is in registers
+        // this wave's pieces of step h+1 landed; steps h+2, h+3 may stay in flight
+        if (h + 3 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kPiecesPerWave) : "memory");
+        else if (h + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerWave) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < nkt) issue_slab((kt + 2) * kBKh, kt & 1);   // nobody reads this slab any more
-        read_b(next, 0);                                         // stale on the last slab, unused
+        if (h + 4 < nsteps) issue_step(h + 4, slot);  // nobody reads step h's buffer any more
+        read_b(next, par ^ 1);                        // stale on the last step, unused
         read_a(next, 0, ah[cur ^ 1], al[cur ^ 1]);
       } else {
-        read_a(base, g + 1, ah[cur ^ 1], al[cur ^ 1]);
-        if (g == 2) read_b(base, 1);
+        read_a(base, x + 1, ah[cur ^ 1], al[cur ^ 1]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int y = 0; y < 2; ++y) {
-        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[ks][y], acc[x][y], 0, 0, 0);
-        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[ks][y], acc[x][y], 0, 0, 0);
-        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[ks][y], acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[par][y], acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[par][y], acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[par][y], acc[x][y], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+  };
+  // two steps per trip: the B-fragment parity is then a compile-time constant
+  // (4 groups per step keep the A current/next parity aligned by themselves)
+  for (int h = 0; h < nsteps; h += 2) {
+    step(h, 0);
+    if (h + 1 < nsteps) step(h + 1, 1);
   }
 
-  // ---- epilogue: acc[x][y][r] = D[M0 + 32x + i'][N0 + 2 l31 + y],
-  // i' = (r & 3) + 8 (r >> 2) + 4 kg; bias (nnet.cc:32-35), ReLU (nnet.cc:56-58)
+  // ---- epilogue: acc[x][y][r] = D[M0 + 32x + i'][N0 + y], N0 = n0 + wn*64 + 2 l31,
+  // i' = (r & 3) + 8 (r >> 2) + 4 kg; bias (nnet.cc:32-35), ReLU (nnet.cc:56-58).  The
+  // (N0, N0 + 1) pair sits in one 8-k chunk of the interleaved row: hi pair at chunk*16 +
+  // N0 % 8 halves, lo pair 8 halves further.
   const int M0 = m0 + wm * 128, N0 = n0 + wn * 64 + 2 * l31;
   const f32x2 bias = *reinterpret_cast<const f32x2 *>(a.bias + N0);
+  const int pair_off = (N0 >> 3) * 16 + (N0 & 7);
 #pragma unroll
   for (int x = 0; x < 4; ++x)
 #pragma unroll
@@ -210,25 +228,28 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
         *reinterpret_cast<f32x2 *>(a.out_f32 + (int64_t)m * a.ldo + N0) = f32x2{v0, v1};
       } else {
         const SplitOut s0 = Split(v0), s1 = Split(v1);
-        *reinterpret_cast<f16x2 *>(a.out_hi + (int64_t)m * a.ldo + N0) = f16x2{s0.hi, s1.hi};
-        *reinterpret_cast<f16x2 *>(a.out_lo + (int64_t)m * a.ldo + N0) = f16x2{s0.lo, s1.lo};
+        _Float16 *orow = a.out + (int64_t)m * a.ldo + pair_off;
+        *reinterpret_cast<f16x2 *>(orow) = f16x2{s0.hi, s1.hi};
+        *reinterpret_cast<f16x2 *>(orow + 8) = f16x2{s0.lo, s1.lo};
       }
     }
 }
 
-// fp32 -> (hi, lo) fp16 pairs.  in: element (r, c) at in[r * stride_r + c * stride_c];
-// out: [rows][ld_out] frame-major, columns >= cols zero-filled up to cols_pad.
+// fp32 -> interleaved (hi, lo) fp16 rows.  in: element (r, c) at in[r * stride_r + c *
+// stride_c]; out row r starts at out + r * ld_out (halves); logical column c lives at
+// (c / 8) * 16 + c % 8 (hi) and 8 halves further (lo); columns cols..cols_pad-1 are zero.
 __global__ void SplitKernel(const float *__restrict__ in, int64_t stride_r, int64_t stride_c,
-                            int rows, int cols, int cols_pad, _Float16 *__restrict__ hi,
-                            _Float16 *__restrict__ lo, int64_t ld_out) {
+                            int rows, int cols, int cols_pad, _Float16 *__restrict__ out,
+                            int64_t ld_out) {
   const int64_t total = (int64_t)rows * cols_pad;
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int r = idx / cols_pad, c = idx % cols_pad;
     const float v = c < cols ? in[(int64_t)r * stride_r + (int64_t)c * stride_c] : 0.0f;
     const SplitOut s = Split(v);
-    hi[(int64_t)r * ld_out + c] = s.hi;
-    lo[(int64_t)r * ld_out + c] = s.lo;
+    _Float16 *o = out + (int64_t)r * ld_out + (c >> 3) * 16 + (c & 7);
+    o[0] = s.hi;
+    o[8] = s.lo;
   }
 }
 
@@ -238,7 +259,7 @@ void LaunchGemmF16(const GemmF16Args &a, hipStream_t stream) {
   const int super_m = (a.tiles_m + 3) / 4, super_n = (a.tiles_n + 3) / 4;
   const int nblk = super_m * super_n * 16;
   dim3 grid(nblk), block(kThreadsF16);
-  const size_t lds = 2 * kSlabBytes;
+  const size_t lds = kRingF16 * kHalfSlabBytes;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmF16Kernel<true, false>),
@@ -261,13 +282,13 @@ void LaunchGemmF16(const GemmF16Args &a, hipStream_t stream) {
 }
 
 void LaunchSplitF16(const float *in, int64_t stride_r, int64_t stride_c, int rows, int cols,
-                    int cols_pad, void *hi, void *lo, int64_t ld_out, hipStream_t stream) {
+                    int cols_pad, _Float16 *out, int64_t ld_out, hipStream_t stream) {
   if (rows <= 0 || cols_pad <= 0) return;
   int64_t n = (int64_t)rows * cols_pad;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(SplitKernel, dim3(blocks), dim3(256), 0, stream, in, stride_r, stride_c, rows,
-                     cols, cols_pad, static_cast<_Float16 *>(hi), static_cast<_Float16 *>(lo), ld_out);
+                     cols, cols_pad, out, ld_out);
 }
 
 }  // namespace pkmi

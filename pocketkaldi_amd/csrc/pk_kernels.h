@@ -68,31 +68,34 @@ void LaunchGemm(const GemmArgs &a, hipStream_t stream);
 // ---------------------------------------------------------------- affine GEMM, f16x3 mode
 
 constexpr int kTileF16 = 256;   // block tile edge of the split-fp16 kernel
-constexpr int kBKF16 = 32;      // its k-step; K is padded to a multiple of this
+constexpr int kBKF16 = 16;      // its k-step (one MFMA k16); K is padded to a multiple of this
 
 // D[m][n] = sum_k X[m][k] * W[n][k] + bias[n] (ReLU), X and W carried as fp16 (hi, lo)
 // pairs, fp32 accumulation on the fp16 matrix cores (see gemm_f16.hip).
-// X: [rows][ldx] (k contiguous; ldx = 40 for the spliced layer-1 view), W: [N pad][ldw].
-// Output: fp32 rows (out_f32 != nullptr, last layer) or the next layer's (hi, lo) pair.
+// Rows are "interleaved": logical k lives at (k / 8) * 16 + k % 8 (hi) and 8 halves
+// further (lo), so a row of K values takes 2 K halves.  X: [rows][ldx] (ldx in halves;
+// 2 * 40 for the spliced layer-1 view), W: [N pad][ldw].
+// Output: fp32 rows (out_f32 != nullptr, last layer) or the next layer's interleaved rows.
 struct GemmF16Args {
-  const _Float16 *Xh, *Xl;
+  const _Float16 *X;
   int64_t ldx;
-  const _Float16 *Wh, *Wl;
+  const _Float16 *W;
   int64_t ldw;
   int K;                 // multiple of kBKF16
   const float *bias;     // [N pad]
   int relu;
   float *out_f32;
-  _Float16 *out_hi, *out_lo;
-  int64_t ldo;
+  _Float16 *out;
+  int64_t ldo;           // floats (out_f32) or halves (out)
   int tiles_m, tiles_n;  // 256 x 256 tiles
 };
 void LaunchGemmF16(const GemmF16Args &a, hipStream_t stream);
 
-// fp32 -> (hi, lo) fp16 pairs: element (r, c) read at in[r * stride_r + c * stride_c],
-// written to hi/lo[r * ld_out + c]; columns cols..cols_pad-1 are zero-filled.
+// fp32 -> interleaved (hi, lo) fp16 rows: element (r, c) read at in[r * stride_r + c *
+// stride_c]; row r of the output starts at out + r * ld_out (halves); columns
+// cols..cols_pad-1 are zero-filled (cols_pad multiple of 8).
 void LaunchSplitF16(const float *in, int64_t stride_r, int64_t stride_c, int rows, int cols,
-                    int cols_pad, void *hi, void *lo, int64_t ld_out, hipStream_t stream);
+                    int cols_pad, _Float16 *out, int64_t ld_out, hipStream_t stream);
 
 // ---------------------------------------------------------------- row-wise / elementwise
 
