@@ -76,91 +76,112 @@ __device__ __forceinline__ float WaveSum(float v) {
 }
 
 constexpr int kTailThreads = 256;
-constexpr int kTailCache = 8;      // float4s per thread kept in registers (n <= 8192)
+constexpr int kTailCacheMax = 8;   // float4s per thread kept in registers (n <= 8192)
 
-// One workgroup per frame.  The row is read once (16-byte loads), kept in
-// registers, reduced with wavefront shuffles + a 4-entry LDS exchange, written once.
-template <int MODE>
+// A workgroup walks rows blockIdx.x, + gridDim.x, ...  A row is read once (16-byte loads),
+// kept in registers, reduced with wavefront shuffles + a 4-entry LDS exchange, written
+// once; the loads of the next row are issued before the current row is reduced, so every
+// CU keeps ~2 rows per resident workgroup in flight towards HBM.
+template <int MODE, int kTailCache>   // kTailCache float4s per thread hold one row (n <= 1024 kTailCache)
 __global__ __launch_bounds__(kTailThreads) void TailKernel(const float *__restrict__ in,
-                                                           int64_t ld_in, int n,
+                                                           int64_t ld_in, int rows, int n,
                                                            const float *__restrict__ log_prior,
                                                            float scale, float *__restrict__ out,
                                                            int64_t ld_out) {
-  __shared__ float red[kTailThreads / 64];
-  const int row = blockIdx.x;
+  __shared__ float red[2][kTailThreads / 64];
   const int tid = threadIdx.x;
-  const float *x = in + (int64_t)row * ld_in;
-  float *y = out + (int64_t)row * ld_out;
   const int n4 = (n + 3) / 4;                    // ld_in is padded, tail lanes masked below
   const float kLogFloor = -46.051701859880914f;  // logf(1e-20f), am.cc:109-110
+  const bool vec_out = ((ld_out & 3) == 0) && ((n & 3) == 0);
 
-  f32x4 v[kTailCache];
-  float m = -INFINITY;
+  // log priors of this thread's columns do not change from row to row
+  f32x4 lp[kTailCache];
 #pragma unroll
   for (int c = 0; c < kTailCache; ++c) {
     const int q = tid + c * kTailThreads;
-    if (q < n4) {
-      v[c] = reinterpret_cast<const f32x4 *>(x)[q];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (q * 4 + e < n) m = fmaxf(m, v[c][e]);
-    }
+    for (int e = 0; e < 4; ++e)
+      lp[c][e] = (MODE != kTailSoftmaxProb && q < n4 && q * 4 + e < n) ? log_prior[q * 4 + e] : 0.0f;
   }
 
-  float lse = 0.0f, inv = 0.0f;
-  if (MODE != kTailLoglik) {
-    m = WaveMax(m);
-    if ((tid & 63) == 0) red[tid >> 6] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    float s = 0.0f;
+  f32x4 v[kTailCache], nv[kTailCache];
+  auto load_row = [&](int row, f32x4 (&dst)[kTailCache]) {
+    const f32x4 *x = reinterpret_cast<const f32x4 *>(in + (int64_t)row * ld_in);
+#pragma unroll
+    for (int c = 0; c < kTailCache; ++c) {
+      const int q = tid + c * kTailThreads;
+      if (q < n4) dst[c] = x[q];
+    }
+  };
+  int row = blockIdx.x;
+  if (row < rows) load_row(row, v);
+  for (; row < rows; row += gridDim.x) {
+    const int next = row + gridDim.x;
+    if (next < rows) load_row(next, nv);
+    float *y = out + (int64_t)row * ld_out;
+
+    float m = -INFINITY, lse = 0.0f, inv = 0.0f;
+    if (MODE != kTailLoglik) {
+#pragma unroll
+      for (int c = 0; c < kTailCache; ++c) {
+        const int q = tid + c * kTailThreads;
+        if (q < n4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (q * 4 + e < n) m = fmaxf(m, v[c][e]);
+        }
+      }
+      m = WaveMax(m);
+      if ((tid & 63) == 0) red[0][tid >> 6] = m;
+      __syncthreads();
+      m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+      float s = 0.0f;
+#pragma unroll
+      for (int c = 0; c < kTailCache; ++c) {
+        const int q = tid + c * kTailThreads;
+        if (q < n4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (q * 4 + e < n) s += expf(v[c][e] - m);
+        }
+      }
+      s = WaveSum(s);
+      if ((tid & 63) == 0) red[1][tid >> 6] = s;
+      __syncthreads();
+      s = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+      lse = m + logf(s);
+      inv = 1.0f / s;
+    }
+
 #pragma unroll
     for (int c = 0; c < kTailCache; ++c) {
       const int q = tid + c * kTailThreads;
       if (q < n4) {
+        f32x4 r;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (q * 4 + e < n) s += expf(v[c][e] - m);
-      }
-    }
-    s = WaveSum(s);
-    if ((tid & 63) == 0) red[tid >> 6] = s;
-    __syncthreads();
-    s = (red[0] + red[1]) + (red[2] + red[3]);
-    lse = m + logf(s);
-    inv = 1.0f / s;
-  }
-
-  const bool vec_out = ((ld_out & 3) == 0) && ((n & 3) == 0);
-#pragma unroll
-  for (int c = 0; c < kTailCache; ++c) {
-    const int q = tid + c * kTailThreads;
-    if (q < n4) {
-      f32x4 r;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int col = q * 4 + e;
-        float t = v[c][e];
-        if (MODE == kTailSoftmaxProb) {
-          t = expf(t - m) * inv;
-        } else {
-          if (MODE == kTailSoftmaxLoglik) t = t - lse;          // log softmax, stable form
-          else t = logf(t < 1.0e-20f ? 1.0e-20f : t);           // am.cc:109-110
-          if (t < kLogFloor) t = kLogFloor;                      // floor of am.cc:109 in the log domain
-          const float lp = col < n ? log_prior[col] : 0.0f;
-          t = (t + -1.0f * lp) * scale;                          // am.cc:111, decodable.cc:15
+        for (int e = 0; e < 4; ++e) {
+          float t = v[c][e];
+          if (MODE == kTailSoftmaxProb) {
+            t = expf(t - m) * inv;
+          } else {
+            if (MODE == kTailSoftmaxLoglik) t = t - lse;          // log softmax, stable form
+            else t = logf(t < 1.0e-20f ? 1.0e-20f : t);           // am.cc:109-110
+            if (t < kLogFloor) t = kLogFloor;                      // floor of am.cc:109 in the log domain
+            t = (t + -1.0f * lp[c][e]) * scale;                    // am.cc:111, decodable.cc:15
+          }
+          r[e] = t;
         }
-        r[e] = t;
-      }
-      if (vec_out) {
-        reinterpret_cast<f32x4 *>(y)[q] = r;
-      } else {
+        if (vec_out) {
+          reinterpret_cast<f32x4 *>(y)[q] = r;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (q * 4 + e < n) y[q * 4 + e] = r[e];
+          for (int e = 0; e < 4; ++e)
+            if (q * 4 + e < n) y[q * 4 + e] = r[e];
+        }
       }
     }
+#pragma unroll
+    for (int c = 0; c < kTailCache; ++c) v[c] = nv[c];
   }
 }
 
@@ -218,22 +239,31 @@ void LaunchTransposeToCols(const float *in, int64_t ld_in, int frames, int dim, 
                      ld_out);
 }
 
+template <int MODE>
+static void LaunchTailMode(const float *in, int64_t ld_in, int rows, int n, const float *log_prior,
+                           float scale, float *out, int64_t ld_out, hipStream_t stream) {
+  dim3 grid(rows < 4096 ? rows : 4096), block(kTailThreads);   // ~16 resident workgroups per CU
+  const int n4 = (n + 3) / 4;
+  if (n4 <= kTailThreads)
+    hipLaunchKernelGGL((TailKernel<MODE, 1>), grid, block, 0, stream, in, ld_in, rows, n, log_prior, scale, out, ld_out);
+  else if (n4 <= 3 * kTailThreads)
+    hipLaunchKernelGGL((TailKernel<MODE, 3>), grid, block, 0, stream, in, ld_in, rows, n, log_prior, scale, out, ld_out);
+  else
+    hipLaunchKernelGGL((TailKernel<MODE, kTailCacheMax>), grid, block, 0, stream, in, ld_in, rows, n, log_prior, scale, out, ld_out);
+}
+
 void LaunchTail(int mode, const float *in, int64_t ld_in, int rows, int n, const float *log_prior,
                 float scale, float *out, int64_t ld_out, hipStream_t stream) {
   if (rows <= 0 || n <= 0) return;
-  dim3 grid(rows), block(kTailThreads);
   switch (mode) {
     case kTailSoftmaxProb:
-      hipLaunchKernelGGL(TailKernel<kTailSoftmaxProb>, grid, block, 0, stream, in, ld_in, n,
-                         log_prior, scale, out, ld_out);
+      LaunchTailMode<kTailSoftmaxProb>(in, ld_in, rows, n, log_prior, scale, out, ld_out, stream);
       break;
     case kTailSoftmaxLoglik:
-      hipLaunchKernelGGL(TailKernel<kTailSoftmaxLoglik>, grid, block, 0, stream, in, ld_in, n,
-                         log_prior, scale, out, ld_out);
+      LaunchTailMode<kTailSoftmaxLoglik>(in, ld_in, rows, n, log_prior, scale, out, ld_out, stream);
       break;
     default:
-      hipLaunchKernelGGL(TailKernel<kTailLoglik>, grid, block, 0, stream, in, ld_in, n, log_prior,
-                         scale, out, ld_out);
+      LaunchTailMode<kTailLoglik>(in, ld_in, rows, n, log_prior, scale, out, ld_out, stream);
       break;
   }
 }
