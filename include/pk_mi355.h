@@ -239,6 +239,23 @@ int pk_mi355_batch_get_timing(pk_mi355_batch_t *b, float ms[PK_MI355_K_COUNT],
 /* algorithmic FLOPs of the affine layers per frame (2 * sum K*N)                 */
 double pk_mi355_am_flops_per_frame(const pk_mi355_am_t *am);
 
+/* ------------------------------------------------------------------------- */
+/* The acoustic half of pk_process (pocketkaldi.cc:176-218) and its input reader   */
+/* ------------------------------------------------------------------------- */
+
+/* pk_16kpcm_read, pcm_reader.cc:45-220: strict 44-byte-header RIFF/WAVE PCM, mono,
+ * 16 kHz, 8/16/32-bit; samples are stored unscaled as float.  pcm_data->data is
+ * (re)allocated with realloc().  Host only, needs no GPU.                          */
+int pk_mi355_16kpcm_read(const char *filename, pk_vector_t *pcm_data);
+
+/* Stages 1-3 of pk_process fused on the device: raw_wave -> fbank -> CMVN -> nnet ->
+ * decodable (host log_prob, ready for Decoder::Decode).  An empty wave gives an empty
+ * decodable (pocketkaldi.cc:180-184).  verbose != 0 prints the reference's per-stage
+ * lines ("Fbank: ..ms", "CMVN: ..ms", "NNET: ..ms", pocketkaldi.cc:194,206,218) to stderr. */
+int pk_mi355_process_acoustic(pk_mi355_am_t *am, const pk_vector_t *cmvn_global_stats,
+                              const pk_vector_t *raw_wave, float prob_scale, pk_decodable_t *out,
+                              int verbose);
+
 /* Library / device facts */
 int pk_mi355_device_count(void);
 const char *pk_mi355_version(void);

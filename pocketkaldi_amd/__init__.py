@@ -22,7 +22,7 @@ import numpy as np
 
 from . import build as _build
 
-__all__ = ["PkError", "lib", "lib_path", "Fbank", "CMVN", "AcousticModel", "Decodable",
+__all__ = ["PkError", "lib", "lib_path", "read_wav", "process_acoustic", "Fbank", "CMVN", "AcousticModel", "Decodable",
            "BatchScorer", "num_frames", "LINEAR", "RELU", "NORMALIZE", "SOFTMAX", "KINDS"]
 
 LINEAR, RELU, NORMALIZE, SOFTMAX = 0, 1, 2, 3
@@ -64,7 +64,8 @@ EXPORTS = [
     "pk_mi355_batch_fetch", "pk_mi355_batch_fetch_fbank", "pk_mi355_batch_fetch_cmvn",
     "pk_mi355_batch_gather_loglik", "pk_mi355_device_malloc", "pk_mi355_device_free", "pk_mi355_memcpy",
     "pk_mi355_batch_stream", "pk_mi355_batch_enable_timing", "pk_mi355_batch_get_timing",
-    "pk_mi355_am_flops_per_frame", "pk_mi355_device_count", "pk_mi355_version",
+    "pk_mi355_am_flops_per_frame", "pk_mi355_16kpcm_read", "pk_mi355_process_acoustic",
+    "pk_mi355_device_count", "pk_mi355_version",
 ]
 
 
@@ -150,6 +151,9 @@ def lib():
     L.pk_mi355_batch_stream.argtypes = [C.c_void_p]
     L.pk_mi355_batch_enable_timing.argtypes = [C.c_void_p, C.c_int]
     L.pk_mi355_batch_get_timing.argtypes = [C.c_void_p, f32p, C.POINTER(C.c_int)]
+    L.pk_mi355_16kpcm_read.argtypes = [C.c_char_p, C.POINTER(pk_vector_t)]
+    L.pk_mi355_process_acoustic.argtypes = [C.c_void_p, C.POINTER(pk_vector_t), C.POINTER(pk_vector_t), C.c_float,
+                                            C.POINTER(pk_decodable_t), C.c_int]
     _lib = L
     return L
 
@@ -196,6 +200,26 @@ def set_device(device):
 def num_frames(num_samples):
     """Fbank::CalcNumFrames (fbank.cc:35-42)."""
     return lib().pk_mi355_num_frames(int(num_samples))
+
+
+def read_wav(path):
+    """pk_16kpcm_read (pcm_reader.cc:45-220) -> float32 samples (unscaled)."""
+    v = pk_vector_t(0, None)
+    _check(lib().pk_mi355_16kpcm_read(path.encode(), C.byref(v)))
+    out = np.ctypeslib.as_array(v.data, shape=(max(v.dim, 1),))[:v.dim].copy()
+    _libc.free(v.data)
+    return out
+
+
+def process_acoustic(am, global_stats, wave, prob_scale=0.1, verbose=False):
+    """Stages 1-3 of pk_process (pocketkaldi.cc:186-218) fused on the device -> Decodable."""
+    g, w = _f32(global_stats), _f32(wave)
+    gv = pk_vector_t(g.shape[0], _fp(g))
+    wv = pk_vector_t(w.shape[0], _fp(w) if w.size else None)
+    d = pk_decodable_t()
+    _check(lib().pk_mi355_process_acoustic(am.handle, C.byref(gv), C.byref(wv), float(prob_scale),
+                                           C.byref(d), 1 if verbose else 0))
+    return Decodable._from_struct(d, am)
 
 
 class Fbank:

@@ -173,6 +173,9 @@ struct pk_mi355_am {
   size_t logprior_off = 0;
   double flops_per_frame = 0;
   Workspace *ws = nullptr;         // single-utterance workspace of pk_decodable_init
+  struct pk_mi355_batch *proc = nullptr;   // cached 1-utterance scorer of pk_mi355_process_acoustic
+  int64_t proc_cap = 0;
+  float proc_stats[41] = {0};
 };
 
 namespace {
@@ -533,6 +536,7 @@ pk_mi355_am_t *pk_mi355_am_create(void) {
 void pk_mi355_am_destroy(pk_mi355_am_t *am) {
   if (!am) return;
   hipSetDevice(am->device);
+  if (am->proc) pk_mi355_batch_destroy(am->proc);
   FreeWorkspace(am->ws);
   hipFree(am->d_blob);
   hipFree(am->d_tid2pdf);
@@ -1274,6 +1278,86 @@ int pk_mi355_cmvn_apply(const pk_vector_t *global_stats, const pk_matrix_t *raw,
       for (int d = 0; d < kNumBins; ++d) out->data[(size_t)t * kNumBins + d] = tmp[(size_t)d * T + t];
   hipFree(d_raw); hipFree(d_g); hipFree(d_ctab); hipFree(d_yt); hipFree(d_i64); hipFree(d_T);
   return ret;
+}
+
+// ------------------------------------------------------------------ pk_process, acoustic half
+
+// pcm_reader.cc:45-220: strict 44-byte-header RIFF/WAVE PCM, mono, 16 kHz, 8/16/32-bit,
+// sample values kept unscaled as float.
+int pk_mi355_16kpcm_read(const char *filename, pk_vector_t *pcm_data) {
+  if (!filename || !pcm_data) return Fail(PK_MI355_E_INVALID, "null argument");
+  FileBuf f;
+  int rc = f.Open(filename);
+  if (rc) return rc;
+  const unsigned char *b = f.d.data();
+  const long size = (long)f.d.size();
+  auto i32 = [&](long off) { int32_t v; memcpy(&v, b + off, 4); return v; };
+  auto i16 = [&](long off) { int16_t v; memcpy(&v, b + off, 2); return (int)v; };
+  if (size < 44) return Fail(PK_MI355_E_IO, "file too short for a WAVE header: %s", filename);
+  if (memcmp(b, "RIFF", 4)) return Fail(PK_MI355_E_IO, "chunk_name == 'RIFF' expected: %s", filename);
+  if (i32(4) != size - 8) return Fail(PK_MI355_E_IO, "chunk_size == %ld expected, but %d found: %s", size - 8, i32(4), filename);
+  if (memcmp(b + 8, "WAVE", 4)) return Fail(PK_MI355_E_IO, "Format == 'WAVE' expected: %s", filename);
+  if (memcmp(b + 12, "fmt ", 4)) return Fail(PK_MI355_E_IO, "subchunk1 == 'fmt ' expected: %s", filename);
+  if (i32(16) != 16) return Fail(PK_MI355_E_IO, "subchunk1_size == 16 expected, but %d found: %s", i32(16), filename);
+  if (i16(20) != 1) return Fail(PK_MI355_E_IO, "audio_format == 1 (PCM) expected, but %d found: %s", i16(20), filename);
+  if (i16(22) != 1) return Fail(PK_MI355_E_IO, "num_channels == 1 (mono) expected, but %d found: %s", i16(22), filename);
+  const int rate = i32(24);
+  if (rate != kSampleRate) return Fail(PK_MI355_E_IO, "sample_rate == 16000 expected, but %d found: %s", rate, filename);
+  const int byte_rate = i32(28), align = i16(32), bits = i16(34);
+  if (bits != 8 && bits != 16 && bits != 32)
+    return Fail(PK_MI355_E_IO, "bits_per_sample == 8, 16 or 32 expected, but %d found: %s", bits, filename);
+  if (byte_rate != rate * bits / 8) return Fail(PK_MI355_E_IO, "bytes_rate == %d expected, but %d found: %s", rate * bits / 8, byte_rate, filename);
+  if (align != bits / 8) return Fail(PK_MI355_E_IO, "block_align == %d expected, but %d found: %s", bits / 8, align, filename);
+  if (memcmp(b + 36, "data", 4)) return Fail(PK_MI355_E_IO, "subchunk2 == 'data' expected: %s", filename);
+  if (i32(40) != size - 44) return Fail(PK_MI355_E_IO, "subchunk2_size == %ld expected, but %d found: %s", size - 44, i32(40), filename);
+  const int n = (int)((size - 44) / (bits / 8));
+  float *s = static_cast<float *>(realloc(pcm_data->data, sizeof(float) * (n > 0 ? n : 1)));
+  if (!s) return Fail(PK_MI355_E_INVALID, "out of host memory");
+  const unsigned char *p = b + 44;
+  for (int i = 0; i < n; ++i) {
+    if (bits == 8) { s[i] = (float)(int8_t)p[0]; p += 1; }
+    else if (bits == 16) { int16_t v; memcpy(&v, p, 2); s[i] = (float)v; p += 2; }
+    else { int32_t v; memcpy(&v, p, 4); s[i] = (float)v; p += 4; }
+  }
+  pcm_data->data = s;
+  pcm_data->dim = n;
+  return 0;
+}
+
+// The three acoustic stages of pk_process (pocketkaldi.cc:186-218) fused on the device:
+// wave -> fbank -> CMVN -> nnet -> decodable.  With verbose != 0 the reference's stage
+// lines go to stderr ("Fbank: ..ms", "CMVN: ..ms", "NNET: ..ms"), timed with HIP events.
+int pk_mi355_process_acoustic(pk_mi355_am_t *am, const pk_vector_t *cmvn_global_stats,
+                              const pk_vector_t *raw_wave, float prob_scale, pk_decodable_t *out,
+                              int verbose) {
+  if (!am || !cmvn_global_stats || !raw_wave || !out) return Fail(PK_MI355_E_INVALID, "null argument");
+  if (cmvn_global_stats->dim != kNumBins + 1) return Fail(PK_MI355_E_INVALID, "cmvn_global_stats must have 41 entries");
+  out->am = am;
+  out->log_prob.ncol = 0; out->log_prob.nrow = 0; out->log_prob.data = nullptr;
+  if (raw_wave->dim == 0) return 0;                           // pocketkaldi.cc:180-184
+  const int64_t need = std::max<int64_t>(raw_wave->dim, 16000);
+  if (!am->proc || need > am->proc_cap ||
+      memcmp(am->proc_stats, cmvn_global_stats->data, sizeof(am->proc_stats)) != 0) {
+    if (am->proc) pk_mi355_batch_destroy(am->proc);
+    am->proc_cap = std::max<int64_t>(need, 2 * am->proc_cap);
+    am->proc = pk_mi355_batch_create(am, cmvn_global_stats->data, 1, am->proc_cap);
+    if (!am->proc) { am->proc_cap = 0; return PK_MI355_E_DEVICE; }
+    memcpy(am->proc_stats, cmvn_global_stats->data, sizeof(am->proc_stats));
+  }
+  pk_mi355_batch *b = am->proc;
+  int rc = pk_mi355_batch_set_waves(b, raw_wave, 1);
+  if (rc) return rc;
+  pk_mi355_batch_enable_timing(b, verbose);
+  if ((rc = pk_mi355_batch_score(b, prob_scale, 1))) return rc;
+  if (verbose) {
+    float ms[PK_MI355_K_COUNT];
+    int launches[PK_MI355_K_COUNT];
+    if ((rc = pk_mi355_batch_get_timing(b, ms, launches))) return rc;
+    fprintf(stderr, "Fbank: %lfms\n", (double)ms[PK_MI355_K_FBANK]);
+    fprintf(stderr, "CMVN: %lfms\n", (double)ms[PK_MI355_K_CMVN]);
+    fprintf(stderr, "NNET: %lfms\n", (double)(ms[PK_MI355_K_GEMM] + ms[PK_MI355_K_TAIL] + ms[PK_MI355_K_OTHER]));
+  }
+  return pk_mi355_batch_fetch(b, 0, out);
 }
 
 }  // extern "C"

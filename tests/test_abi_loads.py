@@ -60,3 +60,51 @@ def test_compute_fails_loudly_without_gpu():
     with pytest.raises(pk.PkError):
         pk.AcousticModel([("linear", np.eye(4, dtype=np.float32), np.zeros(4, np.float32))],
                          prior=np.full(4, 0.25, np.float32))
+
+
+# ---- WAV ingestion is host-only (pcm_reader.cc:45-220): checked here without a GPU
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def test_wav_reader_reference_facts():
+    w = pk.read_wav(os.path.join(GOLDEN, "en-us-hello.wav"))
+    assert w.dtype == np.float32 and w.shape == (7802,)
+    assert list(w[:3]) == [12, 38, -8]
+    from oracle import oracle as O
+    assert np.array_equal(w, O.wav_read(os.path.join(GOLDEN, "en-us-hello.wav")))
+    assert np.array_equal(pk.read_wav(os.path.join(GOLDEN, "en-us-cat.wav")),
+                          O.wav_read(os.path.join(GOLDEN, "en-us-cat.wav")))
+
+
+def test_wav_reader_rejects_what_the_reference_rejects(tmp_path):
+    good = open(os.path.join(GOLDEN, "en-us-hello.wav"), "rb").read()
+
+    def write(name, data):
+        p = tmp_path / name
+        p.write_bytes(data)
+        return str(p)
+
+    import struct
+    cases = {
+        "riff": b"RIFX" + good[4:],
+        "size": good[:4] + struct.pack("<i", 1) + good[8:],
+        "stereo": good[:22] + struct.pack("<h", 2) + good[24:],
+        "rate": good[:24] + struct.pack("<i", 8000) + good[28:],
+        "data": good[:40] + struct.pack("<i", 10) + good[44:],
+        "short": good[:20],
+    }
+    for name, data in cases.items():
+        with pytest.raises(pk.PkError):
+            pk.read_wav(write(name + ".wav", data))
+    with pytest.raises(pk.PkError):
+        pk.read_wav(str(tmp_path / "missing.wav"))
+    # 8-bit and 32-bit PCM are accepted, unscaled
+    n = 100
+    for bits, fmt, vals in ((8, "b", [-5, 7]), (32, "i", [-70000, 123456])):
+        payload = b"".join(struct.pack("<" + fmt, vals[i % 2]) for i in range(n))
+        hdr = (b"RIFF" + struct.pack("<i", 36 + len(payload)) + b"WAVEfmt " +
+               struct.pack("<ihhiihh", 16, 1, 1, 16000, 16000 * bits // 8, bits // 8, bits) +
+               b"data" + struct.pack("<i", len(payload)))
+        w = pk.read_wav(write("pcm%d.wav" % bits, hdr + payload))
+        assert list(w[:2]) == vals and w.shape == (n,)

@@ -420,3 +420,27 @@ def test_device_side_loglikelihood_gather():
         assert bits_equal(out, want)
         for p in (df, dt, do):
             L_.pk_mi355_device_free(p)
+
+
+def test_process_acoustic_matches_staged_path(capfd):
+    """stages 1-3 of pk_process (pocketkaldi.cc:186-218) fused, with the
+    reference's per-stage stderr lines."""
+    layers, prior, L, R, tid2pdf = tiny_model()
+    am = pk.AcousticModel(layers, prior, L, R, tid2pdf)
+    stats = O.read_vec(os.path.join(G, "cmvn_stats.bin"))
+    wave = pk.read_wav(os.path.join(G, "en-us-hello.wav"))
+    d = pk.process_acoustic(am, stats, wave, 0.1, verbose=True)
+    err = capfd.readouterr().err
+    assert "Fbank: " in err and "CMVN: " in err and "NNET: " in err
+    ref = O.Nnet(layers).am_compute(O.cmvn(stats, O.Fbank().compute(wave)), prior, L, R, 0.1)
+    assert_loglik_close(d.log_prob(), ref)
+    assert d.is_last_frame(46) and not d.is_last_frame(-1)
+    # staged path through the class mirror gives the same bits
+    staged = pk.Decodable(am, 0.1, pk.CMVN(stats, pk.Fbank().compute(wave)).get_frames())
+    assert bits_equal(staged.log_prob(), d.log_prob())
+    # empty utterance (pocketkaldi.cc:180-184) and a longer second call (workspace regrowth)
+    assert pk.process_acoustic(am, stats, np.zeros(0, np.float32)).log_prob().shape[0] == 0
+    w2 = synth.utterance(7, 4.0)
+    d2 = pk.process_acoustic(am, stats, w2)
+    ref2 = O.Nnet(layers).am_compute(O.cmvn(stats, O.Fbank().compute(w2)), prior, L, R, 0.1)
+    assert_loglik_close(d2.log_prob(), ref2)
