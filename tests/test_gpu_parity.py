@@ -444,3 +444,45 @@ def test_process_acoustic_matches_staged_path(capfd):
     d2 = pk.process_acoustic(am, stats, w2)
     ref2 = O.Nnet(layers).am_compute(O.cmvn(stats, O.Fbank().compute(w2)), prior, L, R, 0.1)
     assert_loglik_close(d2.log_prob(), ref2)
+
+
+# ------------------------------------------------------------------ BASELINE shapes at full size
+
+def test_wide_model_both_precisions_vs_oracle():
+    """BASELINE configs[4] shape: 440 -> 6 x 2048 ReLU -> 8000 softmax (K = 2048: four 512-chunks)."""
+    layers, prior, L, R = synth.model("W")
+    feats = np.random.default_rng(3).standard_normal((70, 40)).astype(np.float32)
+    ref = O.Nnet(layers).am_compute(feats, prior, L, R, 0.1)
+    for prec in ("f32", "f16x3"):
+        lp = pk.Decodable(pk.AcousticModel(layers, prior, L, R, precision=prec), 0.1, feats).log_prob()
+        assert_loglik_close(lp, ref)
+        assert np.max(np.abs(lp - ref)) < 2e-5
+
+
+def test_full_size_batch_properties():
+    """BASELINE configs[2]: 256 utterances x 10 s, model S.  Too big for the oracle, so the check is
+    through size-independent properties: (i) every frame's likelihoods re-normalise
+    (logsumexp(ll / scale + log prior) == 0), (ii) an utterance scored inside the batch has the
+    same bits as the same utterance scored alone, (iii) a sample of utterances against the oracle."""
+    layers, prior, L, R = synth.model("S")
+    g = synth.global_cmvn_stats()
+    B = 256
+    waves = [synth.utterance(u, 10.0) for u in range(B)]
+    am = pk.AcousticModel(layers, prior, L, R)
+    bs = pk.BatchScorer(am, g, B, sum(len(w) for w in waves))
+    bs.set_waves(waves)
+    bs.score(0.1)
+    assert bs.total_frames() == B * 998
+    logp = np.log(prior.astype(np.float64))
+    solo = pk.BatchScorer(am, g, 1, 160000)
+    for u in (0, 1, 127, 255):
+        ll = bs.fetch(u).log_prob()
+        assert ll.shape == (998, 3000)
+        z = ll.astype(np.float64) / np.float64(np.float32(0.1)) + logp
+        lse = np.log(np.sum(np.exp(z - z.max(axis=1, keepdims=True)), axis=1)) + z.max(axis=1)
+        assert np.max(np.abs(lse)) < 2e-4                       # (i)
+        solo.set_waves([waves[u]])
+        solo.score(0.1)
+        assert bits_equal(solo.fetch(0).log_prob(), ll)         # (ii)
+    ref = O.Nnet(layers).am_compute(O.cmvn(g, O.Fbank().compute(waves[255])), prior, L, R, 0.1)
+    assert_loglik_close(bs.fetch(255).log_prob(), ref)          # (iii)
