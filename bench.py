@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--model", default="S", choices=["S", "W", "tiny"])
     ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
                     help="f32: bit-exact fp32 MFMA (default); f16x3: split-fp16 on the fp16 matrix cores")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo = rehearsal of the multi-rank flow, e.g. two ranks on ONE GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-precision", action="store_true",
                     help="skip the supplementary run in the other precision mode")
@@ -92,10 +94,13 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    pk.set_device(local_rank)
-    pkdist.init("nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)        # rehearsal: several ranks may share one GPU
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    pk.set_device(dev_index)
+    pkdist.init(args.backend)
+    cdev = dev if args.backend == "nccl" else "cpu"   # where the small scalar collectives live
 
     # ---- model: every rank builds the same structure; only rank 0 has real values
     layers, prior, L, R = synth.model(args.model)
@@ -126,7 +131,7 @@ def main():
         chk.set_waves([synth.utterance(0, 1.0)])
         chk.score(0.1)
         s = float(np.sum(chk.fetch(0).log_prob().astype(np.float64)))
-        if not pkdist.all_ranks_agree(s, dev):
+        if not pkdist.all_ranks_agree(s, cdev):
             raise SystemExit("weight broadcast mismatch across ranks")
         chk.close()
 
@@ -145,10 +150,10 @@ def main():
         pkdist.barrier()
         elapsed = time.perf_counter() - t0
         tm_ = scorer.timing()          # events of the LAST step (each score() resets the recorder)
-        return pkdist.max_over_ranks(elapsed, dev), tm_
+        return pkdist.max_over_ranks(elapsed, cdev), tm_
 
     dt, tm = timed_steps(bs)
-    total_frames = pkdist.sum_over_ranks(frames_per_step, dev)
+    total_frames = pkdist.sum_over_ranks(frames_per_step, cdev)
 
     # ---- supplementary: the same workload in the other precision mode (same K, W)
     other = None

@@ -142,10 +142,12 @@ __global__ __launch_bounds__(kThreads, 3) void GemmKernel(GemmArgs a) {
     }
   };
   auto mfma4 = [&](const float (&pf)[kBK / 4][2], const float (&qf)[kBK / 4][2], int ks) {
+    __builtin_amdgcn_s_setprio(1);
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[ks][0], qf[ks][0], acc[0][0], 0, 0, 0);
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[ks][0], qf[ks][1], acc[0][1], 0, 0, 0);
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[ks][1], qf[ks][0], acc[1][0], 0, 0, 0);
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[ks][1], qf[ks][1], acc[1][1], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- software pipeline.  Per slab kt (A = k-steps 0..3, B = k-steps 4..7):

@@ -40,9 +40,15 @@ def utterance_ids(rank, world, per_rank):
 
 
 def broadcast_blob(blob_u8, src=0):
-    """The one collective of the path: rank `src`'s weight blob to every rank, in place."""
+    """The one collective of the path: rank `src`'s weight blob to every rank, in place.
+    (With the gloo rehearsal backend a device tensor is staged through the host.)"""
     if dist.is_initialized():
-        dist.broadcast(blob_u8, src=src)
+        if blob_u8.is_cuda and dist.get_backend() == "gloo":
+            host = blob_u8.cpu()
+            dist.broadcast(host, src=src)
+            blob_u8.copy_(host)
+        else:
+            dist.broadcast(blob_u8, src=src)
     return blob_u8
 
 
