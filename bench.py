@@ -196,7 +196,8 @@ def main():
                                    % (args.batch, args.seconds, nh, hidden, pdfs),
                        "model": args.model, "utterances_per_gpu": args.batch,
                        "frames_per_gpu_per_step": int(frames_per_step),
-                       "parallelism": "utterance-sharded x%d, weights broadcast once (RCCL)" % world},
+                       "parallelism": "utterance-sharded x%d, weights broadcast once (%s)" % (
+                           world, "RCCL" if args.backend == "nccl" else "gloo rehearsal")},
             "roofline": {"bound": "mfma",
                          "kernel": ("GemmKernel (fp32 MFMA affine layers, %d launches/step)" if args.precision == "f32" else
                                     "GemmF16Kernel (fp16 MFMA, 3 MFMA per algorithmic product, %d launches/step)") % gemm_launches,
