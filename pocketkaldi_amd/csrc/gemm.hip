@@ -21,7 +21,9 @@
 // Tile: 128 x 128 per 256-thread workgroup (4 waves as 2 x 2, 64 x 64 per wave =
 // 2 x 2 MFMA tiles with interleaved rows), BK = 16, a ring of three LDS slabs
 // (48 KiB) with two slabs of DMA in flight, one raw s_barrier per slab, three
-// workgroups per CU.
+// workgroups per CU.  When a launch has too few 128 x 128 tiles to fill the chip
+// (a single utterance: 8 x 8 tiles for 256 CUs) the same kernel runs with 64 x 64
+// tiles (one MFMA tile per wave, S = 1) -- four times the workgroups.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -37,49 +39,60 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 256;
-constexpr int kSlab = kBK * kTile;          // floats per operand per slab
 constexpr int kRing = 3;                    // LDS slabs in the ring
-constexpr int kDmaPerWave = 4;              // x4 DMA pieces one wave issues per slab
 
 typedef const __attribute__((address_space(1))) void *GlobalPtr;
 typedef __attribute__((address_space(3))) void *LdsPtr;
 
-// One slab (16 k-rows of both operands) goes into ring slot `slot` as kDma DMA
-// "pieces" per wave, so that the pieces can be spread between MFMAs.  A x4
-// wave-instruction moves 64 lanes x 16 B = two 512-byte k-rows; wave w owns rows
-// 4w..4w+3 of P and of Q.  The LDS destination is wave-uniform base + lane * 16
-// (hardware), the global source is per lane.
-template <bool SPLICE>
+// Geometry for S x S MFMA tiles per wave (S = 2: 128 x 128 block tile, S = 1: 64 x 64).
+template <int S>
+struct Geo {
+  static constexpr int kBT = 64 * S;               // block tile edge
+  static constexpr int kSlab = kBK * kBT;          // floats per operand per slab
+  static constexpr int kPieceRows = 4 / S;         // k-rows one 1 KiB DMA piece covers
+  static constexpr int kLanesPerRow = 16 * S;      // lanes (x 16 B) per k-row of a piece
+  static constexpr int kDma = 2 * S;               // pieces one wave issues per slab (S for P, S for Q)
+};
+
+// One slab (16 k-rows of both operands) goes into ring slot `slot` as kDma DMA "pieces"
+// per wave, so that the pieces can be spread between MFMAs.  A x4 wave-instruction moves
+// 64 lanes x 16 B = 1 KiB = kPieceRows k-rows; wave w owns rows 4w..4w+3 of P and of Q.
+// The LDS destination is wave-uniform base + lane * 16 (hardware), the global source is
+// per lane.
+template <int S, bool SPLICE>
 __device__ __forceinline__ void IssuePiece(const GemmArgs &a, const float *__restrict__ pg,
                                            const float *__restrict__ qg, int k0, int wave, int lane,
                                            uint32_t lane_off_p, uint32_t lane_off_q, float *smem,
                                            int slot, int piece) {
-  float *ps = smem + (slot * 2 + 0) * kSlab;
-  float *qs = smem + (slot * 2 + 1) * kSlab;
+  using G = Geo<S>;
+  float *ps = smem + (slot * 2 + 0) * G::kSlab;
+  float *qs = smem + (slot * 2 + 1) * G::kSlab;
   // Plain panels: wave-uniform 64-bit row base (scalar registers) + a loop-invariant
   // 32-bit per-lane byte offset, so a piece costs scalar address math only.
-  if (piece < 2) {                                    // P rows, x4
-    const int row = wave * 4 + piece * 2;             // wave-uniform
+  if (piece < S) {                                    // P rows
+    const int row = wave * 4 + piece * G::kPieceRows; // wave-uniform
     const char *base = reinterpret_cast<const char *>(pg + (int64_t)(k0 + row) * a.ldp);
-    __builtin_amdgcn_global_load_lds((GlobalPtr)(base + lane_off_p), (LdsPtr)(ps + row * kTile), 16, 0, 0);
-  } else if (!SPLICE) {                               // Q rows, x4
-    const int row = wave * 4 + (piece - 2) * 2;
+    __builtin_amdgcn_global_load_lds((GlobalPtr)(base + lane_off_p), (LdsPtr)(ps + row * G::kBT), 16, 0, 0);
+  } else if (!SPLICE) {                               // Q rows
+    const int row = wave * 4 + (piece - S) * G::kPieceRows;
     const char *base = reinterpret_cast<const char *>(qg + (int64_t)(k0 + row) * a.ldq);
-    __builtin_amdgcn_global_load_lds((GlobalPtr)(base + lane_off_q), (LdsPtr)(qs + row * kTile), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((GlobalPtr)(base + lane_off_q), (LdsPtr)(qs + row * G::kBT), 16, 0, 0);
   } else {
     // am.cc:65-88 without materialising: operand row k is feature (k % D) of the
     // padded feature-major matrix, shifted by (k / D) frames.  The source is only
     // 4-byte aligned; x4 LDS-DMA takes that on gfx950 (bit-exact in the parity tests).
-    const int row = wave * 4 + (piece - 2) * 2;
-    const int k = k0 + row + (lane >> 5);
+    const int row = wave * 4 + (piece - S) * G::kPieceRows;
+    const int k = k0 + row + lane / G::kLanesPerRow;
     const int c = k / a.splice_dim, d = k - c * a.splice_dim;
-    __builtin_amdgcn_global_load_lds((GlobalPtr)(qg + (int64_t)d * a.ldq + c + (lane & 31) * 4),
-                                     (LdsPtr)(qs + row * kTile), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((GlobalPtr)(qg + (int64_t)d * a.ldq + c + (lane % G::kLanesPerRow) * 4),
+                                     (LdsPtr)(qs + row * G::kBT), 16, 0, 0);
   }
 }
 
-template <bool SPLICE, bool MULTICHUNK, bool BIAS_J, bool RELU>
+template <int S, bool SPLICE, bool MULTICHUNK, bool BIAS_J, bool RELU>
 __global__ __launch_bounds__(kThreads, 3) void GemmKernel(GemmArgs a) {
+  using G = Geo<S>;
+  constexpr int kBT = G::kBT, kSlab = G::kSlab, kDma = G::kDma;
   // ALL LDS in one array (a second __shared__ object makes hipcc drain the DMA
   // queue before every LDS read)
   __shared__ __attribute__((aligned(16))) float smem[kRing * 2 * kSlab];
@@ -88,15 +101,16 @@ __global__ __launch_bounds__(kThreads, 3) void GemmKernel(GemmArgs a) {
   // dispatch), so give each XCD a contiguous run of ids, and walk ids through
   // 8 x 8 super-tiles: the 64 workgroups resident on one XCD then share 8 P
   // panels and 8 Q panels in that XCD's L2.  Placement affects speed only.
+  const int tiles_i = a.tiles_i * (2 / S), tiles_j = a.tiles_j * (2 / S);   // args count 128-tiles
   const int nblk = gridDim.x;                       // multiple of 64
   const int b = blockIdx.x;
   const int wg = (b % 8) * (nblk / 8) + b / 8;
-  const int super_i = (a.tiles_i + 7) / 8;
+  const int super_i = (tiles_i + 7) / 8;
   const int s = wg / 64, w = wg % 64;
   const int ti = (s % super_i) * 8 + (w % 8);
   const int tj = (s / super_i) * 8 + (w / 8);
-  if (ti >= a.tiles_i || tj >= a.tiles_j) return;
-  const int i0 = ti * kTile, j0 = tj * kTile;
+  if (ti >= tiles_i || tj >= tiles_j) return;
+  const int i0 = ti * kBT, j0 = tj * kBT;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -105,60 +119,66 @@ __global__ __launch_bounds__(kThreads, 3) void GemmKernel(GemmArgs a) {
   const int half = lane >> 5, l31 = lane & 31;
   const float *pg = a.P + i0;
   const float *qg = a.Q + j0;
-  // byte offset of this lane inside a two-row DMA piece (rows k, k+1; 16 bytes per lane)
-  const uint32_t lane_off_p = (uint32_t)(((lane >> 5) * a.ldp + (lane & 31) * 4) * sizeof(float));
-  const uint32_t lane_off_q = (uint32_t)(((lane >> 5) * a.ldq + (lane & 31) * 4) * sizeof(float));
+  // byte offset of this lane inside a DMA piece (kPieceRows k-rows, 16 bytes per lane)
+  const uint32_t lane_off_p = (uint32_t)(((lane / G::kLanesPerRow) * a.ldp + (lane % G::kLanesPerRow) * 4) * sizeof(float));
+  const uint32_t lane_off_q = (uint32_t)(((lane / G::kLanesPerRow) * a.ldq + (lane % G::kLanesPerRow) * 4) * sizeof(float));
 
-  f32x16 acc[2][2], done[2][2];
+  f32x16 acc[S][S], done[S][S];
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+  for (int x = 0; x < S; ++x)
 #pragma unroll
-    for (int y = 0; y < 2; ++y) {
+    for (int y = 0; y < S; ++y) {
       acc[x][y] = f32x16{0};
       done[x][y] = f32x16{0};
     }
 
   const int nkt = a.K / kBK;
-  constexpr int kDma = kDmaPerWave;
 
   auto issue_slab = [&](int kt, int slot) {
 #pragma unroll
     for (int p = 0; p < kDma; ++p)
-      IssuePiece<SPLICE>(a, pg, qg, kt * kBK, wave, lane, lane_off_p, lane_off_q, smem, slot, p);
+      IssuePiece<S, SPLICE>(a, pg, qg, kt * kBK, wave, lane, lane_off_p, lane_off_q, smem, slot, p);
   };
   // fragments of k-steps [first, first+4) of the slab in `slot`.  Sub-tile a of a wave
-  // takes the rows I0 + 2 i' + a (i' = lane & 31), so the two P values (and the two Q
-  // values) a lane needs are adjacent: one 8-byte LDS read each, conflict-free, all
-  // k-steps reachable through the instruction's immediate offset.
-  auto read_frags = [&](int slot, int first, float (&pf)[kBK / 4][2], float (&qf)[kBK / 4][2]) {
-    const f32x2 *ps = reinterpret_cast<const f32x2 *>(smem + (slot * 2 + 0) * kSlab + wi * 64 + 2 * l31 + half * kTile);
-    const f32x2 *qs = reinterpret_cast<const f32x2 *>(smem + (slot * 2 + 1) * kSlab + wj * 64 + 2 * l31 + half * kTile);
+  // takes the rows I0 + S i' + a (i' = lane & 31), so the S values of P (and of Q) a lane
+  // needs are adjacent: one LDS read each (8 bytes for S = 2), conflict-free, all k-steps
+  // reachable through the instruction's immediate offset.
+  auto read_frags = [&](int slot, int first, float (&pf)[kBK / 4][S], float (&qf)[kBK / 4][S]) {
+    const float *ps = smem + (slot * 2 + 0) * kSlab + wi * (32 * S) + S * l31 + half * kBT;
+    const float *qs = smem + (slot * 2 + 1) * kSlab + wj * (32 * S) + S * l31 + half * kBT;
 #pragma unroll
     for (int ks = 0; ks < kBK / 4; ++ks) {
-      const int kk = (first + ks) * kTile;            // in float2 units: 2 k-rows = 2 * 128 floats
-      const f32x2 p = ps[kk], q = qs[kk];
-      pf[ks][0] = p[0]; pf[ks][1] = p[1];
-      qf[ks][0] = q[0]; qf[ks][1] = q[1];
+      const int kk = 2 * (first + ks) * kBT;
+      if (S == 2) {
+        const f32x2 p = *reinterpret_cast<const f32x2 *>(ps + kk);
+        const f32x2 q = *reinterpret_cast<const f32x2 *>(qs + kk);
+        pf[ks][0] = p[0]; pf[ks][S - 1] = p[1];
+        qf[ks][0] = q[0]; qf[ks][S - 1] = q[1];
+      } else {
+        pf[ks][0] = ps[kk];
+        qf[ks][0] = qs[kk];
+      }
     }
   };
-  auto mfma4 = [&](const float (&pf)[kBK / 4][2], const float (&qf)[kBK / 4][2], int ks) {
+  auto mfma_step = [&](const float (&pf)[kBK / 4][S], const float (&qf)[kBK / 4][S], int ks) {
     __builtin_amdgcn_s_setprio(1);
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[ks][0], qf[ks][0], acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[ks][0], qf[ks][1], acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[ks][1], qf[ks][0], acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[ks][1], qf[ks][1], acc[1][1], 0, 0, 0);
+#pragma unroll
+    for (int x = 0; x < S; ++x)
+#pragma unroll
+      for (int y = 0; y < S; ++y)
+        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[ks][x], qf[ks][y], acc[x][y], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- software pipeline.  Per slab kt (A = k-steps 0..3, B = k-steps 4..7):
-  //   16 MFMA on A(kt) with the reads of frags B(kt) and the DMA pieces of slab kt+2 between them
-  //   | wait DMA(kt+1), barrier | read frags A(kt+1) | 16 MFMA on B(kt)
-  // Two workgroups share each SIMD and run in lockstep, so anything outside the MFMA
-  // stream is idle matrix-pipe time: DMA issue and fragment reads are tucked under
-  // MFMAs, and only the barrier itself is exposed.
+  //   MFMAs on A(kt) with the reads of frags B(kt) and the DMA pieces of slab kt+2 between them
+  //   | wait DMA(kt+1), barrier | read frags A(kt+1) | MFMAs on B(kt)
+  // Workgroups sharing a SIMD run in lockstep, so anything outside the MFMA stream is
+  // idle matrix-pipe time: DMA issue and fragment reads are tucked under MFMAs, and only
+  // the barrier itself is exposed.
   // Slot reuse: DMA(kt+2) overwrites the slot of slab kt-1, whose last reads every
   // wave completed (lgkmcnt(0)) before the barrier of slab kt-1.
-  float fa_p[kBK / 4][2], fa_q[kBK / 4][2], fb_p[kBK / 4][2], fb_q[kBK / 4][2];
+  float fa_p[kBK / 4][S], fa_q[kBK / 4][S], fb_p[kBK / 4][S], fb_q[kBK / 4][S];
   issue_slab(0, 0);
   if (nkt > 1) {
     issue_slab(1, 1);
@@ -177,7 +197,7 @@ __global__ __launch_bounds__(kThreads, 3) void GemmKernel(GemmArgs a) {
     const bool dma = kt + 2 < nkt;
 #pragma unroll
     for (int ks = 0; ks < kBK / 4; ++ks) {
-      mfma4(fa_p, fa_q, ks);
+      mfma_step(fa_p, fa_q, ks);
       __builtin_amdgcn_sched_barrier(0);
       // B fragments are fetched behind the first MFMAs (issued before them, hipcc
       // waits for them -- lgkmcnt(0) -- ahead of the first MFMA)
@@ -185,7 +205,7 @@ __global__ __launch_bounds__(kThreads, 3) void GemmKernel(GemmArgs a) {
       if (dma) {
 #pragma unroll
         for (int p = ks * kDma / 4; p < (ks + 1) * kDma / 4; ++p)
-          IssuePiece<SPLICE>(a, pg, qg, (kt + 2) * kBK, wave, lane, lane_off_p, lane_off_q, smem, slot2, p);
+          IssuePiece<S, SPLICE>(a, pg, qg, (kt + 2) * kBK, wave, lane, lane_off_p, lane_off_q, smem, slot2, p);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -203,15 +223,15 @@ __global__ __launch_bounds__(kThreads, 3) void GemmKernel(GemmArgs a) {
                                         // here makes hipcc wait lgkmcnt(0) ahead of the MFMAs below
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ks = 0; ks < kBK / 4; ++ks) mfma4(fb_p, fb_q, ks);
+    for (int ks = 0; ks < kBK / 4; ++ks) mfma_step(fb_p, fb_q, ks);
 
     if (MULTICHUNK && kt + 1 < nkt && ((kt + 1) * kBK) % kChunkK == 0) {
       // gemm.cc:95-123: a finished 512-chunk is added into C (first chunk: stored)
       const bool first = (kt + 1) * kBK == kChunkK;
 #pragma unroll
-      for (int x = 0; x < 2; ++x)
+      for (int x = 0; x < S; ++x)
 #pragma unroll
-        for (int y = 0; y < 2; ++y) {
+        for (int y = 0; y < S; ++y) {
           done[x][y] = first ? acc[x][y] : done[x][y] + acc[x][y];
           acc[x][y] = f32x16{0};
         }
@@ -221,67 +241,77 @@ __global__ __launch_bounds__(kThreads, 3) void GemmKernel(GemmArgs a) {
   }
 
   // ---- epilogue.  Accumulator acc[x][y], register r, lane (l31, half) holds
-  // D[I0 + 2 i' + x][J0 + 2 l31 + y] with i' = (r & 3) + 8 (r >> 2) + 4 half: the y = 0/1
-  // pair is adjacent in memory, so a row is written as 32 lanes x 8 bytes = 256 contiguous
-  // bytes per store.  The bias values are fetched in one batch (a per-element runtime
-  // select makes hipcc branch around every load and wait for each one).
-  const int I0 = i0 + wi * 64, J0 = j0 + wj * 64;
-  f32x2 bj = {0.0f, 0.0f};
-  float bi[2][16];
+  // D[I0 + S i' + x][J0 + S l31 + y] with i' = (r & 3) + 8 (r >> 2) + 4 half: the y values
+  // are adjacent in memory, so (S = 2) a row is written as 32 lanes x 8 bytes = 256
+  // contiguous bytes per store.  The bias values are fetched in one batch (a per-element
+  // runtime select makes hipcc branch around every load and wait for each one).
+  const int I0 = i0 + wi * (32 * S), J0 = j0 + wj * (32 * S);
+  float bj[S];
+  float bi[S][16];
   if (BIAS_J) {
-    bj = *reinterpret_cast<const f32x2 *>(a.bias + J0 + 2 * l31);
+#pragma unroll
+    for (int y = 0; y < S; ++y) bj[y] = a.bias[J0 + S * l31 + y];
   } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const f32x2 t = *reinterpret_cast<const f32x2 *>(a.bias + I0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * half));
-      bi[0][r] = t[0];
-      bi[1][r] = t[1];
-    }
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int x = 0; x < S; ++x)
+        bi[x][r] = a.bias[I0 + S * ((r & 3) + 8 * (r >> 2) + 4 * half) + x];
   }
 #pragma unroll
-  for (int x = 0; x < 2; ++x) {
-    float *obase = a.out + (int64_t)(I0 + 8 * half + x) * a.ldo + J0 + 2 * l31;
+  for (int x = 0; x < S; ++x) {
+    float *obase = a.out + (int64_t)(I0 + S * 4 * half + x) * a.ldo + J0 + S * l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      f32x2 v;
+      float v[S];
 #pragma unroll
-      for (int y = 0; y < 2; ++y) {
+      for (int y = 0; y < S; ++y) {
         float t = acc[x][y][r];
         if (MULTICHUNK) t = done[x][y][r] + t;
         t += BIAS_J ? bj[y] : bi[x][r];                // nnet.cc:32-35
         if (RELU) t = t < 0.0f ? 0.0f : t;             // nnet.cc:56-58
         v[y] = t;
       }
-      *reinterpret_cast<f32x2 *>(obase + (int64_t)(2 * ((r & 3) + 8 * (r >> 2))) * a.ldo) = v;
+      float *dst = obase + (int64_t)(S * ((r & 3) + 8 * (r >> 2))) * a.ldo;
+      if (S == 2) *reinterpret_cast<f32x2 *>(dst) = f32x2{v[0], v[S - 1]};
+      else dst[0] = v[0];
     }
   }
 }
 
-template <bool SPLICE, bool MULTICHUNK>
+template <int S, bool SPLICE, bool MULTICHUNK>
 void LaunchVariant(const GemmArgs &a, dim3 grid, dim3 block, hipStream_t stream) {
   if (a.bias_on_j) {
-    if (a.relu) hipLaunchKernelGGL((GemmKernel<SPLICE, MULTICHUNK, true, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((GemmKernel<SPLICE, MULTICHUNK, true, false>), grid, block, 0, stream, a);
+    if (a.relu) hipLaunchKernelGGL((GemmKernel<S, SPLICE, MULTICHUNK, true, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((GemmKernel<S, SPLICE, MULTICHUNK, true, false>), grid, block, 0, stream, a);
   } else {
-    if (a.relu) hipLaunchKernelGGL((GemmKernel<SPLICE, MULTICHUNK, false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((GemmKernel<SPLICE, MULTICHUNK, false, false>), grid, block, 0, stream, a);
+    if (a.relu) hipLaunchKernelGGL((GemmKernel<S, SPLICE, MULTICHUNK, false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((GemmKernel<S, SPLICE, MULTICHUNK, false, false>), grid, block, 0, stream, a);
+  }
+}
+
+template <int S>
+void LaunchGeo(const GemmArgs &a, hipStream_t stream) {
+  const int ti = a.tiles_i * (2 / S), tj = a.tiles_j * (2 / S);
+  const int super_i = (ti + 7) / 8, super_j = (tj + 7) / 8;
+  const int nblk = super_i * super_j * 64;
+  const bool multi = a.K > kChunkK;
+  dim3 grid(nblk), block(kThreads);
+  if (a.splice_dim > 0) {
+    if (multi) LaunchVariant<S, true, true>(a, grid, block, stream);
+    else LaunchVariant<S, true, false>(a, grid, block, stream);
+  } else {
+    if (multi) LaunchVariant<S, false, true>(a, grid, block, stream);
+    else LaunchVariant<S, false, false>(a, grid, block, stream);
   }
 }
 
 }  // namespace
 
 void LaunchGemm(const GemmArgs &a, hipStream_t stream) {
-  const int super_i = (a.tiles_i + 7) / 8, super_j = (a.tiles_j + 7) / 8;
-  const int nblk = super_i * super_j * 64;
-  const bool multi = a.K > kChunkK;
-  dim3 grid(nblk), block(kThreads);
-  if (a.splice_dim > 0) {
-    if (multi) LaunchVariant<true, true>(a, grid, block, stream);
-    else LaunchVariant<true, false>(a, grid, block, stream);
-  } else {
-    if (multi) LaunchVariant<false, true>(a, grid, block, stream);
-    else LaunchVariant<false, false>(a, grid, block, stream);
-  }
+  // fewer 128 x 128 tiles than ~1.5 per CU: quarter the tile, quadruple the workgroups
+  if (a.tiles_i * a.tiles_j < 384) LaunchGeo<1>(a, stream);
+  else LaunchGeo<2>(a, stream);
 }
 
 }  // namespace pkmi
