@@ -292,69 +292,120 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
   }
 }
 
-// One lane per (utterance, feature); lanes walk the frames in order because the
-// running window sum is rounded to float every frame (cmvn.cc:66-70).  The window
-// count is min(t + 1, 600), so the smoothing weight and the 1/count scale come from
-// the host-built CmvnTables; the serial chain per frame is one fp64 add (two once the
-// window slides), one narrowing, two float multiply-adds.
+// One wavefront per utterance, one lane per feature; lanes walk the frames in order
+// because the running window sum is rounded to float every frame (cmvn.cc:66-70).  The
+// window count is min(t + 1, 600), so the smoothing weight and the 1/count scale come
+// from the host-built CmvnTables; the serial chain per frame is one fp64 add (two once
+// the window slides), one narrowing, two float multiply-adds.
+// Memory never touches the chain: frames move HBM -> LDS in tiles of 64 (contiguous
+// 10 KiB, LDS-DMA, the next tile in flight while the current one is walked), results go
+// LDS -> HBM as 40 rows of 64 consecutive frames (256-byte stores).
+constexpr int kCmvnTile = 64;                                   // frames per tile
+constexpr int kCmvnTileFloats = kCmvnTile * kNumBins;           // 2560 floats = 10 KiB
+constexpr int kCmvnOutLd = kCmvnTile + 1;                       // bank-conflict padding
+
 __global__ __launch_bounds__(kWave) void CmvnKernel(const float *__restrict__ raw, UttLayout utts,
                                                     const float *__restrict__ g,
                                                     const CmvnTables *__restrict__ tab, int left,
                                                     int right, float *__restrict__ yt,
                                                     int64_t ldy) {
-  const int d = threadIdx.x;
+  // ONE LDS array, carved by hand: with several __shared__ objects hipcc waits for the
+  // in-flight LDS-DMA of the next tile before every LDS read of the current one
+  __shared__ __attribute__((aligned(16))) float lds[4 * kCmvnTileFloats + kNumBins * kCmvnOutLd + 2 * kCmvnWindow];
+  float *s_in = lds;                                  // [2][tile]: x[t][d]
+  float *s_old = lds + 2 * kCmvnTileFloats;           // [2][tile]: x[t - 600][d]
+  float *s_out = lds + 4 * kCmvnTileFloats;           // y[d][t]
+  float *s_alpha = s_out + kNumBins * kCmvnOutLd, *s_nscale = s_alpha + kCmvnWindow;
+
+  const int lane = threadIdx.x;
   const int utt = blockIdx.x;
-  if (d >= kNumBins) return;
   const int T = utts.num_frames[utt];
   if (T <= 0) return;
-  const float *x0 = raw + utts.raw_base[utt] * kNumBins + d;
-  float *y0 = yt + (int64_t)d * ldy + utts.pad_base[utt];
+  const float *x0 = raw + utts.raw_base[utt] * kNumBins;
+  float *y0 = yt + utts.pad_base[utt];
+  for (int i = lane; i < kCmvnWindow; i += kWave) { s_alpha[i] = tab->alpha[i]; s_nscale[i] = tab->neg_scale[i]; }
 
+  typedef const __attribute__((address_space(1))) void *GlobalPtr;
+  typedef __attribute__((address_space(3))) void *LdsPtr;
+  const int ntiles = (T + kCmvnTile - 1) / kCmvnTile;
+  // tile `i` of the utterance (and of the frames leaving the window) -> LDS buffer i & 1.
+  // 10 x 1 KiB pieces each; source clamped to the utterance (clamped values are unused).
+  auto fetch = [&](int i) {
+    const int64_t total = (int64_t)T * kNumBins;
+#pragma unroll
+    for (int p = 0; p < kCmvnTileFloats / 256; ++p) {
+      int64_t e = (int64_t)i * kCmvnTileFloats + p * 256 + lane * 4;          // float index in the utterance
+      int64_t ec = e + 4 <= total ? e : total - 4;
+      if (ec < 0) ec = 0;
+      __builtin_amdgcn_global_load_lds((GlobalPtr)(x0 + ec), (LdsPtr)(s_in + (i & 1) * kCmvnTileFloats + p * 256), 16, 0, 0);
+      int64_t o = e - (int64_t)kCmvnWindow * kNumBins;
+      int64_t oc = o < 0 ? 0 : (o + 4 <= total ? o : total - 4);
+      if (oc < 0) oc = 0;
+      __builtin_amdgcn_global_load_lds((GlobalPtr)(x0 + oc), (LdsPtr)(s_old + (i & 1) * kCmvnTileFloats + p * 256), 16, 0, 0);
+    }
+  };
+
+  const int d = lane < kNumBins ? lane : 0;       // lanes 40..63 shadow feature 0 and store nothing
   const float gd = g[d];
   float s = 0.0f;      // cached window sum of this feature
   float y = 0.0f;
-  constexpr int kStage = 8;   // frames per block of loads; the next block is in flight
-                              // while the serial recurrence walks the current one
-  float xs[kStage], xps[kStage], al[kStage], ns[kStage];
-  float nxs[kStage], nxps[kStage], nal[kStage], nns[kStage];
-  auto fetch = [&](int t0, float (&a)[kStage], float (&b)[kStage], float (&c)[kStage],
-                   float (&e)[kStage]) {
-    // none of these loads depends on the recurrence
+  fetch(0);
+  for (int i = 0; i < ntiles; ++i) {
+    // tile i has landed and the stores of tile i-1 are out; then put tile i+1 in flight
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (i + 1 < ntiles) fetch(i + 1);
+    const float *xin = s_in + (i & 1) * kCmvnTileFloats, *xold = s_old + (i & 1) * kCmvnTileFloats;
+    const int t0 = i * kCmvnTile;
+    const int nt = T - t0 < kCmvnTile ? T - t0 : kCmvnTile;
+    // blocks of 8 frames: all LDS operands of the block are fetched first (they do not
+    // depend on the recurrence), so the serial chain is arithmetic only
+    constexpr int kBlk = 8;
+    for (int u0 = 0; u0 < nt; u0 += kBlk) {
+      float xs[kBlk], xo[kBlk], al[kBlk], ns[kBlk];
 #pragma unroll
-    for (int u = 0; u < kStage; ++u) {
-      const int t = t0 + u;
-      const int tt = t < kCmvnWindow ? t : kCmvnWindow - 1;
-      a[u] = t < T ? x0[(int64_t)t * kNumBins] : 0.0f;
-      b[u] = (t < T && t >= kCmvnWindow) ? x0[(int64_t)(t - kCmvnWindow) * kNumBins] : 0.0f;
-      c[u] = tab->alpha[tt];
-      e[u] = tab->neg_scale[tt];
-    }
-  };
-  fetch(0, xs, xps, al, ns);
-  for (int t0 = 0; t0 < T; t0 += kStage) {
-    fetch(t0 + kStage, nxs, nxps, nal, nns);
+      for (int v = 0; v < kBlk; ++v) {
+        const int u = u0 + v < kCmvnTile ? u0 + v : kCmvnTile - 1;
+        const int t = t0 + u;
+        const int tt = t < kCmvnWindow ? t : kCmvnWindow - 1;
+        xs[v] = xin[u * kNumBins + d];
+        xo[v] = xold[u * kNumBins + d];
+        al[v] = s_alpha[tt];
+        ns[v] = s_nscale[tt];
+      }
 #pragma unroll
-    for (int u = 0; u < kStage; ++u) {
-      const int t = t0 + u;
-      if (t < T) {
-        const float x = xs[u];
-        double acc = s;                                 // cmvn.cc:44-52
-        acc += x;
-        if (t >= kCmvnWindow) acc += -1.0 * static_cast<double>(xps[u]);   // cmvn.cc:58-64
-        s = static_cast<float>(acc);                    // cmvn.cc:66-70
-        float st = s;
-        if (t + 1 < kCmvnWindow) st += al[u] * gd;      // cmvn.cc:73-92 (count < window)
-        y = x;
-        y += ns[u] * st;                                // cmvn.cc:94-101
-        y0[left + t] = y;
-        if (t == 0)
-          for (int p = 0; p < left; ++p) y0[p] = y;     // am.cc:73 clamp, done at write time
+      for (int v = 0; v < kBlk; ++v) {
+        const int u = u0 + v, t = t0 + u;
+        if (u < nt) {
+          const float x = xs[v];
+          double acc = s;                                 // cmvn.cc:44-52
+          acc += x;
+          if (t >= kCmvnWindow) acc += -1.0 * static_cast<double>(xo[v]);   // cmvn.cc:58-64
+          s = static_cast<float>(acc);                    // cmvn.cc:66-70
+          float st = s;
+          if (t + 1 < kCmvnWindow) st += al[v] * gd;      // cmvn.cc:73-92 (count < window)
+          y = x;
+          y += ns[v] * st;                                // cmvn.cc:94-101
+          s_out[d * kCmvnOutLd + u] = y;
+          if (t == 0 && lane < kNumBins)
+            for (int p = 0; p < left; ++p) y0[(int64_t)d * ldy + p] = y;   // am.cc:73 clamp, done at write time
+        }
       }
     }
-#pragma unroll
-    for (int u = 0; u < kStage; ++u) { xs[u] = nxs[u]; xps[u] = nxps[u]; al[u] = nal[u]; ns[u] = nns[u]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    // rows of 64 consecutive frames: lane = frame
+    if (lane < nt) {
+#pragma unroll 8
+      for (int dd = 0; dd < kNumBins; ++dd)
+        y0[(int64_t)dd * ldy + left + t0 + lane] = s_out[dd * kCmvnOutLd + lane];
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
   }
-  for (int p = 0; p < right; ++p) y0[left + T + p] = y;   // am.cc:74
+  if (lane < kNumBins)
+    for (int p = 0; p < right; ++p) y0[(int64_t)d * ldy + left + T + p] = y;   // am.cc:74
 }
 
 __global__ void PadTransposeKernel(const float *__restrict__ feats, int T, int dim, int left,
