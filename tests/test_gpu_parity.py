@@ -486,3 +486,28 @@ def test_full_size_batch_properties():
         assert bits_equal(solo.fetch(0).log_prob(), ll)         # (ii)
     ref = O.Nnet(layers).am_compute(O.cmvn(g, O.Fbank().compute(waves[255])), prior, L, R, 0.1)
     assert_loglik_close(bs.fetch(255).log_prob(), ref)          # (iii)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_run_to_run_determinism_under_load(prec):
+    """Race screen for the DMA-ring / barrier structure of the GEMM kernels: the same batch scored
+    40 times back to back (no host sync in between) must give identical bits every time, and
+    those bits must be the ones a freshly built scorer produces."""
+    import zlib
+    layers, prior, L, R = synth.model("S")
+    g = synth.global_cmvn_stats()
+    waves = [synth.utterance(200 + u, 10.0) for u in range(24)]
+    am = pk.AcousticModel(layers, prior, L, R, precision=prec)
+    bs = pk.BatchScorer(am, g, len(waves), sum(len(w) for w in waves))
+    bs.set_waves(waves)
+    sums = set()
+    for rep in range(8):
+        for _ in range(5):
+            bs.score(0.1, sync=False)
+        bs.synchronize()
+        sums.add(tuple(zlib.crc32(bs.fetch(u).log_prob().tobytes()) for u in (0, 11, 23)))
+    assert len(sums) == 1
+    bs2 = pk.BatchScorer(am, g, len(waves), sum(len(w) for w in waves))
+    bs2.set_waves(waves)
+    bs2.score(0.1)
+    assert tuple(zlib.crc32(bs2.fetch(u).log_prob().tobytes()) for u in (0, 11, 23)) in sums
