@@ -160,15 +160,26 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
   const SampleT *w0 = wave_pcm + utts.wave_off[utt];
   float *out0 = raw + utts.raw_base[utt] * kNumBins;
 
-  for (int t = blockIdx.x * kFbankWaves + wv; t < T; t += gridDim.x * kFbankWaves) {
-    // ---- fbank.cc:74-100: the frame's 400 samples, 7 per lane (lane + 64 r)
+  // ---- fbank.cc:74-100: a frame's 400 samples, 7 per lane (lane + 64 r).  The samples of
+  // the wave's NEXT frame are fetched before the current frame is processed.
+  const int t_step = gridDim.x * kFbankWaves;
+  auto fetch = [&](int t, SampleT (&dst)[7]) {
     const SampleT *w = w0 + (int64_t)t * kFrameShift;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      const int i = lane + kWave * r;
+      dst[r] = (t < T && i < kFrameLength) ? w[i] : static_cast<SampleT>(0);
+    }
+  };
+  SampleT cur_s[7], next_s[7];
+  fetch(blockIdx.x * kFbankWaves + wv, cur_s);
+  for (int t = blockIdx.x * kFbankWaves + wv; t < T; t += t_step) {
+    fetch(t + t_step, next_s);
     float x[7];
     bool exact = true;
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
-      int i = lane + kWave * r;
-      x[r] = (i < kFrameLength) ? static_cast<float>(w[i]) : 0.0f;
+      x[r] = static_cast<float>(cur_s[r]);
       // integer-valued samples of at most 16 bits: any summation order is exact
       exact = exact && (fabsf(x[r]) <= 32768.0f) && (x[r] == truncf(x[r]));
     }
@@ -289,6 +300,8 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
       out0[(int64_t)t * kNumBins + lane] = static_cast<float>(log(static_cast<double>(e)));
     }
     WaveSync();
+#pragma unroll
+    for (int r = 0; r < 7; ++r) cur_s[r] = next_s[r];
   }
 }
 
