@@ -511,3 +511,24 @@ def test_run_to_run_determinism_under_load(prec):
     bs2.set_waves(waves)
     bs2.score(0.1)
     assert tuple(zlib.crc32(bs2.fetch(u).log_prob().tobytes()) for u in (0, 11, 23)) in sums
+
+
+def test_long_single_utterance_through_the_reference_entry_point():
+    """pk_decodable_init on an utterance longer than the single-utterance pass (4096 frames) and
+    longer than the CMVN window several times over: the internal row blocks are invisible."""
+    layers, prior, L, R, tid2pdf = tiny_model()
+    rng = np.random.default_rng(17)
+    feats = rng.standard_normal((9001, 40)).astype(np.float32)
+    ref = O.Nnet(layers).am_compute(feats, prior, L, R, 0.1)
+    for prec in ("f32", "f16x3"):
+        am = pk.AcousticModel(layers, prior, L, R, tid2pdf, precision=prec)
+        d = pk.Decodable(am, 0.1, feats)
+        assert_loglik_close(d.log_prob(), ref)
+        assert d.is_last_frame(9000) and not d.is_last_frame(8999)
+    # and the front-end on 95 s of audio (9498 frames, window slides for 8898 of them)
+    w = synth.utterance(300, 95.0)
+    g = synth.global_cmvn_stats()
+    fb = pk.Fbank().compute(w)
+    assert fb.shape == (9498, 40)
+    assert_fbank_close(fb, O.Fbank().compute(w))
+    assert bits_equal(pk.CMVN(g, fb).get_frames(), O.cmvn(g, fb))
