@@ -29,22 +29,29 @@ constexpr int kWave = 64;
 // `base`: srfft.cc:163-173 (radix-2 step), :176-188 (+-j step), :198-222
 // (twiddles).  The reference sweeps each step over the whole block; the quads
 // are disjoint so doing all three steps per quad rounds identically.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// The frame is kept as interleaved complex numbers z[n] = (re, im): the windowed samples
+// y[0..511] ARE that array (srfft.cc:296-303 de-interleaves because its recursion wants
+// split arrays; the arithmetic is the same), and every butterfly moves whole complex
+// values, so each LDS access is one 8-byte word.
 template <int LOGM>
-__device__ __forceinline__ void LButterfly(float *xr, float *xi, int base, int n,
-                                           const float *__restrict__ tw) {
+__device__ __forceinline__ void LButterfly(f32x2 *z, int base, int n, const float *__restrict__ tw) {
   constexpr int m = 1 << LOGM, m2 = m / 2, m4 = m / 4, m8 = m / 8;
   const int i0 = base + n, i1 = i0 + m4, i2 = i0 + m2, i3 = i2 + m4;
+  const f32x2 z0 = z[i0], z1 = z[i1], z2 = z[i2], z3 = z[i3];
 
-  float ar = xr[i0] + xr[i2], br = xr[i0] - xr[i2];
-  float ai = xi[i0] + xi[i2], bi = xi[i0] - xi[i2];
-  float cr = xr[i1] + xr[i3], dr = xr[i1] - xr[i3];
-  float ci = xi[i1] + xi[i3], di = xi[i1] - xi[i3];
-  xr[i0] = ar; xi[i0] = ai; xr[i1] = cr; xi[i1] = ci;
+  float ar = z0[0] + z2[0], br = z0[0] - z2[0];
+  float ai = z0[1] + z2[1], bi = z0[1] - z2[1];
+  float cr = z1[0] + z3[0], dr = z1[0] - z3[0];
+  float ci = z1[1] + z3[1], di = z1[1] - z3[1];
+  z[i0] = f32x2{ar, ai};
+  z[i1] = f32x2{cr, ci};
 
-  float r1 = br + di;   // -> xr[i2]
-  float q2 = bi + dr;   // -> xi[i3]
-  float q1 = bi - dr;   // -> xi[i2]
-  float r2 = br - di;   // -> xr[i3]
+  float r1 = br + di;   // -> re[i2]
+  float q2 = bi + dr;   // -> im[i3]
+  float q1 = bi - dr;   // -> im[i2]
+  float r2 = br - di;   // -> re[i3]
 
   if (LOGM >= 3 && n != 0) {
     if (n == m8) {
@@ -68,7 +75,8 @@ __device__ __forceinline__ void LButterfly(float *xr, float *xi, int base, int n
       q2 = t1;
     }
   }
-  xr[i2] = r1; xi[i2] = q1; xr[i3] = r2; xi[i3] = q2;
+  z[i2] = f32x2{r1, q1};
+  z[i3] = f32x2{r2, q2};
 }
 
 // The constant tables of the front-end, copied once per workgroup into LDS (the
@@ -92,8 +100,7 @@ struct LdsTables {
 // Per-wave work area: one frame.
 struct FrameLds {
   float x[kFrameLength];       // DC-removed samples (pre-emphasis neighbour)
-  float re[kFftCplx];
-  float im[kFftCplx];
+  f32x2 z[kFftCplx];           // the 256 complex points (= the 512 windowed samples)
   float pw[kFftCplx + 4];
 };
 
@@ -108,7 +115,7 @@ __device__ __forceinline__ void WaveSync() {
 }
 
 template <int LOGM>
-__device__ __forceinline__ void FftPass(float *xr, float *xi, int lane, const LdsTables &tab) {
+__device__ __forceinline__ void FftPass(f32x2 *z, int lane, const LdsTables &tab) {
   constexpr int pass = kLogCplx - LOGM;
   constexpr int q = (1 << LOGM) / 4;        // butterflies per block
   const int first = tab.pass_start[pass];
@@ -116,7 +123,7 @@ __device__ __forceinline__ void FftPass(float *xr, float *xi, int lane, const Ld
   const int b = lane / q, n = lane % q;     // q is a power of two
   if (b < nblk) {
     const float *tw = LOGM >= 4 ? tab.tw + tab.tw_off[LOGM] : nullptr;
-    LButterfly<LOGM>(xr, xi, tab.blk_off[first + b], n, tw);
+    LButterfly<LOGM>(z, tab.blk_off[first + b], n, tw);
   }
   WaveSync();
 }
@@ -154,7 +161,9 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   FrameLds &fr = frames[wv];
-  float *s_x = fr.x, *s_re = fr.re, *s_im = fr.im, *s_pow = fr.pw;
+  float *s_x = fr.x, *s_pow = fr.pw;
+  f32x2 *s_z = fr.z;
+  float *s_y = reinterpret_cast<float *>(fr.z);   // the same array as 512 real samples
   const int utt = blockIdx.y;
   const int T = utts.num_frames[utt];
   const SampleT *w0 = wave_pcm + utts.wave_off[utt];
@@ -218,8 +227,8 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
     WaveSync();
 
     // ---- fbank.cc:58-68: pre-emphasis in double (0.97 is a double literal), one
-    // rounding to float, then the Hamming window.  De-interleave into re/im for
-    // the half-size complex FFT (srfft.cc:296-303); zero padding 400..511.
+    // rounding to float, then the Hamming window; zero padding 400..511.  Sample 2n is
+    // the real part and 2n+1 the imaginary part of point n of the half-size complex FFT.
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       int i = lane + kWave * r;
@@ -229,29 +238,26 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
         y = static_cast<float>(static_cast<double>(x[r]) - 0.97 * static_cast<double>(prev));
         y *= tab.window[i];
       }
-      if (i & 1) s_im[i >> 1] = y; else s_re[i >> 1] = y;
+      s_y[i] = y;
     }
     WaveSync();
 
     // ---- srfft.cc:95-237 as passes over the block schedule
-    FftPass<8>(s_re, s_im, lane, tab);
-    FftPass<7>(s_re, s_im, lane, tab);
-    FftPass<6>(s_re, s_im, lane, tab);
-    FftPass<5>(s_re, s_im, lane, tab);
-    FftPass<4>(s_re, s_im, lane, tab);
-    FftPass<3>(s_re, s_im, lane, tab);
-    FftPass<2>(s_re, s_im, lane, tab);
+    FftPass<8>(s_z, lane, tab);
+    FftPass<7>(s_z, lane, tab);
+    FftPass<6>(s_z, lane, tab);
+    FftPass<5>(s_z, lane, tab);
+    FftPass<4>(s_z, lane, tab);
+    FftPass<3>(s_z, lane, tab);
+    FftPass<2>(s_z, lane, tab);
     {   // two-point blocks, srfft.cc:140-150
       const int first = tab.pass_start[kNumPasses - 1];
       const int nblk = tab.pass_start[kNumPasses] - first;
       for (int b = lane; b < nblk; b += kWave) {
         int off = tab.blk_off[first + b];
-        float tr = s_re[off] + s_re[off + 1];
-        s_re[off + 1] = s_re[off] - s_re[off + 1];
-        s_re[off] = tr;
-        float ti = s_im[off] + s_im[off + 1];
-        s_im[off + 1] = s_im[off] - s_im[off + 1];
-        s_im[off] = ti;
+        const f32x2 u0 = s_z[off], u1 = s_z[off + 1];
+        s_z[off] = f32x2{u0[0] + u1[0], u0[1] + u1[1]};
+        s_z[off + 1] = f32x2{u0[0] - u1[0], u0[1] - u1[1]};
       }
     }
     WaveSync();
@@ -263,8 +269,9 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
       const int k = 1 + lane + kWave * r;            // 1..128
       const int kd = kFftCplx - k;
       const int jk = tab.bitrev[k], jd = tab.bitrev[kd];
-      const float bk_re = s_re[jk], bk_im = s_im[jk];
-      const float bd_re = s_re[jd], bd_im = s_im[jd];
+      const f32x2 zk = s_z[jk], zd = s_z[jd];
+      const float bk_re = zk[0], bk_im = zk[1];
+      const float bd_re = zd[0], bd_im = zd[1];
       const float kre = tab.post_re[k], kim = tab.post_im[k];
       const float ck_re = 0.5f * (bk_re + bd_re);
       const float ck_im = 0.5f * (bk_im - bd_im);
@@ -283,7 +290,8 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
       }
     }
     if (lane == 0) {                                 // srfft.cc:444-447, fbank.cc:201-210
-      const float zeroth = s_re[0] + s_im[0], n2th = s_re[0] - s_im[0];
+      const f32x2 z00 = s_z[0];
+      const float zeroth = z00[0] + z00[1], n2th = z00[0] - z00[1];
       s_pow[0] = zeroth * zeroth;
       s_pow[kFftCplx] = n2th * n2th;
     }
