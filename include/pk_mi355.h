@@ -198,6 +198,15 @@ const float *pk_mi355_batch_loglik_device(const pk_mi355_batch_t *b, int utt);
 /* Copy utterance utt's results into a host decodable (malloc'd log_prob), ready
  * for Decoder::Decode (decoder.cc:39).                                           */
 int pk_mi355_batch_fetch(pk_mi355_batch_t *b, int utt, pk_decodable_t *out);
+/* All utterances at once: ONE device-to-host transfer into a page-locked arena the batch owns
+ * (made on first use), and out[0..num_out) (num_out == pk_mi355_batch_num_utts) filled as
+ * decodables whose log_prob VIEWS that arena -- same fields, same [T][num_pdfs] layout, usable
+ * by Decoder::Decode like any other (decoder.cc:39).  pk_decodable_destroy on such a view
+ * frees nothing, and must happen (if at all) before the batch is destroyed.  The views are
+ * valid until the batch is scored again or destroyed.  With
+ * sync == 0 the copy is queued on the batch's stream (after the scoring it follows) and
+ * pk_mi355_batch_synchronize completes it, so it overlaps another batch's scoring.          */
+int pk_mi355_batch_fetch_all(pk_mi355_batch_t *b, pk_decodable_t *out, int num_out, int sync);
 /* Intermediate stages, for parity tests: raw fbank / CMVN'd features of utt,
  * copied to host as [T][40].                                                     */
 int pk_mi355_batch_fetch_fbank(pk_mi355_batch_t *b, int utt, float *out);
@@ -217,6 +226,11 @@ int pk_mi355_batch_gather_loglik(pk_mi355_batch_t *b, int utt, const int32_t *d_
 void *pk_mi355_device_malloc(size_t bytes);
 void pk_mi355_device_free(void *ptr);
 int pk_mi355_memcpy(void *dst, const void *src, size_t bytes, int kind);
+/* Page-locked host memory for PCM handed to pk_mi355_batch_set_waves_i16 / _set_waves: from
+ * such a buffer the upload is a true asynchronous DMA that overlaps another batch's scoring
+ * and result transfer (from pageable memory the runtime stages it and the call blocks).     */
+void *pk_mi355_host_malloc(size_t bytes);
+void pk_mi355_host_free(void *ptr);
 
 /* The HIP stream the batch launches on (hipStream_t as void*), so callers can
  * bracket it with their own events.                                              */

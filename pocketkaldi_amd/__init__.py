@@ -61,8 +61,9 @@ EXPORTS = [
     "pk_mi355_batch_set_waves", "pk_mi355_batch_set_waves_i16", "pk_mi355_batch_set_waves_device",
     "pk_mi355_batch_score", "pk_mi355_batch_synchronize", "pk_mi355_batch_num_utts",
     "pk_mi355_batch_num_frames", "pk_mi355_batch_total_frames", "pk_mi355_batch_loglik_device",
-    "pk_mi355_batch_fetch", "pk_mi355_batch_fetch_fbank", "pk_mi355_batch_fetch_cmvn",
+    "pk_mi355_batch_fetch", "pk_mi355_batch_fetch_all", "pk_mi355_batch_fetch_fbank", "pk_mi355_batch_fetch_cmvn",
     "pk_mi355_batch_gather_loglik", "pk_mi355_device_malloc", "pk_mi355_device_free", "pk_mi355_memcpy",
+    "pk_mi355_host_malloc", "pk_mi355_host_free",
     "pk_mi355_batch_stream", "pk_mi355_batch_enable_timing", "pk_mi355_batch_get_timing",
     "pk_mi355_am_flops_per_frame", "pk_mi355_16kpcm_read", "pk_mi355_process_acoustic",
     "pk_mi355_device_count", "pk_mi355_version",
@@ -139,6 +140,7 @@ def lib():
     L.pk_mi355_batch_loglik_device.restype = C.c_void_p
     L.pk_mi355_batch_loglik_device.argtypes = [C.c_void_p, C.c_int]
     L.pk_mi355_batch_fetch.argtypes = [C.c_void_p, C.c_int, C.POINTER(pk_decodable_t)]
+    L.pk_mi355_batch_fetch_all.argtypes = [C.c_void_p, C.POINTER(pk_decodable_t), C.c_int, C.c_int]
     L.pk_mi355_batch_fetch_fbank.argtypes = [C.c_void_p, C.c_int, f32p]
     L.pk_mi355_batch_fetch_cmvn.argtypes = [C.c_void_p, C.c_int, f32p]
     L.pk_mi355_batch_gather_loglik.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -147,6 +149,10 @@ def lib():
     L.pk_mi355_device_free.restype = None
     L.pk_mi355_device_free.argtypes = [C.c_void_p]
     L.pk_mi355_memcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.pk_mi355_host_malloc.restype = C.c_void_p
+    L.pk_mi355_host_malloc.argtypes = [C.c_size_t]
+    L.pk_mi355_host_free.restype = None
+    L.pk_mi355_host_free.argtypes = [C.c_void_p]
     L.pk_mi355_batch_stream.restype = C.c_void_p
     L.pk_mi355_batch_stream.argtypes = [C.c_void_p]
     L.pk_mi355_batch_enable_timing.argtypes = [C.c_void_p, C.c_int]
@@ -328,6 +334,36 @@ class AcousticModel:
         return _take_matrix(m_out)
 
 
+class _Pinned:
+    def __init__(self, nbytes):
+        self.ptr = lib().pk_mi355_host_malloc(max(int(nbytes), 1))
+        if not self.ptr:
+            raise PkError(lib().pk_mi355_last_error().decode())
+
+    def __del__(self):
+        try:
+            lib().pk_mi355_host_free(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def pinned_i16(n):
+    """An int16 numpy array of n samples in page-locked host memory (pk_mi355_host_malloc)."""
+    owner = _Pinned(2 * int(n))
+    buf = (C.c_int16 * int(n)).from_address(owner.ptr)
+    arr = np.frombuffer(buf, dtype=np.int16)
+    arr = arr.view(_OwnedArray)
+    arr._owner = owner
+    return arr
+
+
+class _OwnedArray(np.ndarray):
+    _owner = None
+
+    def __array_finalize__(self, obj):
+        self._owner = getattr(obj, "_owner", None)
+
+
 class Decodable:
     """decodable.h:15-41 over the C ABI (what decoder.cc consumes)."""
 
@@ -409,6 +445,13 @@ class BatchScorer:
         _check(lib().pk_mi355_batch_set_waves_i16(self._h, cat.ctypes.data_as(C.POINTER(C.c_int16)), ns,
                                                   len(waves)))
 
+    def set_waves_i16_raw(self, samples, num_samples):
+        """Concatenated int16 samples (e.g. a pinned_i16() array) + per-utterance counts; no host copy."""
+        ns = (C.c_int * max(len(num_samples), 1))(*[int(n) for n in num_samples])
+        self._keep = samples
+        _check(lib().pk_mi355_batch_set_waves_i16(self._h, samples.ctypes.data_as(C.POINTER(C.c_int16)), ns,
+                                                  len(num_samples)))
+
     def set_waves_device(self, device_ptr, num_samples, keep_alive=None):
         """PCM already in HBM: device_ptr -> concatenated float samples."""
         ns = (C.c_int * max(len(num_samples), 1))(*[int(n) for n in num_samples])
@@ -440,6 +483,16 @@ class BatchScorer:
         d = pk_decodable_t()
         _check(lib().pk_mi355_batch_fetch(self._h, utt, C.byref(d)))
         return Decodable._from_struct(d, self._am)
+
+    def fetch_all(self, sync=True):
+        """Every utterance's decodable from one transfer into the batch's page-locked arena (views)."""
+        n = self.num_utts()
+        arr = (pk_decodable_t * max(n, 1))()
+        _check(lib().pk_mi355_batch_fetch_all(self._h, arr, n, 1 if sync else 0))
+        out = [Decodable._from_struct(arr[u], self._am) for u in range(n)]
+        for d in out:
+            d._owner = self          # a view must not outlive the batch whose arena it points into
+        return out
 
     def fetch_fbank(self, utt):
         out = np.zeros((self.num_frames(utt), 40), dtype=np.float32)

@@ -10,6 +10,8 @@
 
 #include <algorithm>
 #include <string>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "../../include/pk_mi355.h"
@@ -508,6 +510,41 @@ int ResizeHostMatrix(pk_matrix_t *m, int nrow, int ncol) {
 
 // ================================================================== C ABI
 
+// Page-locked host arenas of live batches (pk_mi355_batch_fetch_all): pk_decodable_destroy must
+// not free() a pointer into one of them.
+namespace {
+std::mutex g_arena_mu;
+std::vector<std::pair<const char *, const char *>> g_arenas;
+
+void RegisterArena(const void *p, size_t bytes) {
+  std::lock_guard<std::mutex> g(g_arena_mu);
+  g_arenas.emplace_back(static_cast<const char *>(p), static_cast<const char *>(p) + bytes);
+}
+void UnregisterArena(const void *p) {
+  std::lock_guard<std::mutex> g(g_arena_mu);
+  for (size_t i = 0; i < g_arenas.size(); ++i)
+    if (g_arenas[i].first == p) { g_arenas.erase(g_arenas.begin() + i); return; }
+}
+// One device-to-host result stream per device (pk_mi355_batch_fetch_all); lives for the process.
+hipStream_t ResultStream(int device) {
+  static hipStream_t streams[64] = {};
+  if (device < 0 || device >= 64) { Fail(PK_MI355_E_INVALID, "device index %d", device); return nullptr; }
+  std::lock_guard<std::mutex> g(g_arena_mu);
+  if (!streams[device]) {
+    hipError_t e = hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking);
+    if (e != hipSuccess) { Fail(PK_MI355_E_DEVICE, "result stream: %s", hipGetErrorString(e)); return nullptr; }
+  }
+  return streams[device];
+}
+bool IsArenaPointer(const void *p) {
+  if (!p) return false;
+  std::lock_guard<std::mutex> g(g_arena_mu);
+  for (const auto &a : g_arenas)
+    if (static_cast<const char *>(p) >= a.first && static_cast<const char *>(p) < a.second) return true;
+  return false;
+}
+}  // namespace
+
 extern "C" {
 
 const char *pk_mi355_last_error(void) { return g_err; }
@@ -826,7 +863,9 @@ void pk_decodable_init(pk_decodable_t *self, pk_mi355_am_t *am, float prob_scale
 }
 
 void pk_decodable_destroy(pk_decodable_t *self) {
-  free(self->log_prob.data);          // matrix.cc:123-128
+  // matrix.cc:123-128 frees; a decodable handed out by pk_mi355_batch_fetch_all is a view of
+  // the batch's page-locked arena and owns nothing.
+  if (!IsArenaPointer(self->log_prob.data)) free(self->log_prob.data);
   self->log_prob.data = nullptr;
   self->log_prob.nrow = 0;
   self->log_prob.ncol = 0;
@@ -876,6 +915,8 @@ struct pk_mi355_batch {
   _Float16 *d_y2 = nullptr;   // f16x3: interleaved (hi, lo) rows [ldy][2 feat_dim]
   int64_t ldy = 0;
   float *d_ll = nullptr;    // [max_cols][num_pdfs]
+  float *h_ll = nullptr;    // page-locked mirror of d_ll (pk_mi355_batch_fetch_all), made on first use
+  hipEvent_t ev_scored = nullptr, ev_fetched = nullptr;
   ExecBufs exec;
   bool scored = false;
 };
@@ -986,6 +1027,9 @@ void pk_mi355_batch_destroy(pk_mi355_batch_t *b) {
   hipFree(b->d_wave); hipFree(b->d_wave_i16);
   hipFree(b->d_wave_off); hipFree(b->d_raw_base); hipFree(b->d_pad_base); hipFree(b->d_T);
   hipFree(b->d_raw); hipFree(b->d_yt); hipFree(b->d_y2); hipFree(b->d_ll);
+  if (b->h_ll) { UnregisterArena(b->h_ll); hipHostFree(b->h_ll); }
+  if (b->ev_scored) hipEventDestroy(b->ev_scored);
+  if (b->ev_fetched) hipEventDestroy(b->ev_fetched);
   if (b->stream) hipStreamDestroy(b->stream);
   delete b;
 }
@@ -1110,6 +1154,48 @@ int pk_mi355_batch_fetch(pk_mi355_batch_t *b, int utt, pk_decodable_t *out) {
   return 0;
 }
 
+int pk_mi355_batch_fetch_all(pk_mi355_batch_t *b, pk_decodable_t *out, int num_out, int sync) {
+  if (!b || !out || num_out != b->num_utts) return Fail(PK_MI355_E_INVALID, "fetch_all: expected %d decodables", b ? b->num_utts : 0);
+  if (!b->scored) return Fail(PK_MI355_E_STATE, "batch not scored");
+  int rc = UseDevice(b->device);
+  if (rc) return rc;
+  const int N = b->am->num_pdfs;
+  if (!b->h_ll) {
+    const size_t bytes = sizeof(float) * (size_t)b->max_cols * N;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_ll), bytes, hipHostMallocDefault));
+    RegisterArena(b->h_ll, bytes);
+  }
+  // One transfer of the used part of d_ll (the 10 rows between two utterances travel too:
+  // 1 % at T = 998, and one large copy runs at the link rate).
+  // The transfer is queued on ONE result stream per device, ordered after this batch's scoring
+  // and before anything later on the batch's stream.  Results of several batches in flight
+  // then leave the device first come, first served at the full link rate -- on their own
+  // streams the copies would share the link, finish together, and the batches would fall into
+  // step (all scoring, then all copying) instead of overlapping.
+  if (b->total_cols > 0) {
+    hipStream_t rs = ResultStream(b->device);
+    if (!rs) return PK_MI355_E_DEVICE;
+    if (!b->ev_scored) {
+      HIP_TRY(hipEventCreateWithFlags(&b->ev_scored, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&b->ev_fetched, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(b->ev_scored, b->stream));
+    HIP_TRY(hipStreamWaitEvent(rs, b->ev_scored, 0));
+    HIP_TRY(hipMemcpyAsync(b->h_ll, b->d_ll, sizeof(float) * (size_t)b->total_cols * N, hipMemcpyDeviceToHost, rs));
+    HIP_TRY(hipEventRecord(b->ev_fetched, rs));
+    HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_fetched, 0));
+  }
+  for (int u = 0; u < num_out; ++u) {
+    const int T = b->h_T[u];
+    out[u].am = b->am;
+    out[u].log_prob.ncol = T;
+    out[u].log_prob.nrow = T > 0 ? N : 0;
+    out[u].log_prob.data = T > 0 ? b->h_ll + (size_t)b->h_pad_base[u] * N : nullptr;
+  }
+  if (sync) HIP_TRY(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
 int pk_mi355_batch_fetch_fbank(pk_mi355_batch_t *b, int utt, float *out) {
   if (!b || !out || utt < 0 || utt >= b->num_utts) return Fail(PK_MI355_E_INVALID, "bad utterance index");
   if (!b->scored) return Fail(PK_MI355_E_STATE, "batch not scored");
@@ -1158,6 +1244,16 @@ void *pk_mi355_device_malloc(size_t bytes) {
 }
 
 void pk_mi355_device_free(void *p) { hipFree(p); }
+
+void *pk_mi355_host_malloc(size_t bytes) {
+  if (UseDevice(g_device)) return nullptr;
+  void *p = nullptr;
+  hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) { Fail(PK_MI355_E_DEVICE, "hipHostMalloc: %s", hipGetErrorString(e)); return nullptr; }
+  return p;
+}
+
+void pk_mi355_host_free(void *p) { hipHostFree(p); }
 
 int pk_mi355_memcpy(void *dst, const void *src, size_t bytes, int kind) {
   hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;

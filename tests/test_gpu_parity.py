@@ -532,3 +532,37 @@ def test_long_single_utterance_through_the_reference_entry_point():
     assert fb.shape == (9498, 40)
     assert_fbank_close(fb, O.Fbank().compute(w))
     assert bits_equal(pk.CMVN(g, fb).get_frames(), O.cmvn(g, fb))
+
+
+def test_fetch_all_views_match_per_utterance_fetch():
+    """pk_mi355_batch_fetch_all: one transfer into the page-locked arena; every view equals the
+    malloc'd decodable pk_mi355_batch_fetch returns, destroy on a view frees nothing, and the
+    arena is refilled by the next score."""
+    layers, prior, L, R = synth.model("tiny")
+    am = pk.AcousticModel(layers, prior, L, R)
+    durs = [0.5, 0.02, 1.3, 0.031, 0.9]          # two utterances shorter than a frame -> T = 0
+    waves = [synth.utterance(40 + u, d) for u, d in enumerate(durs)]
+    bs = pk.BatchScorer(am, synth.global_cmvn_stats(), len(waves), sum(len(w) for w in waves))
+    bs.set_waves(waves)
+    bs.score(0.1, sync=True)
+    views = bs.fetch_all(sync=False)
+    bs.synchronize()
+    tid2pdf_n = am.num_pdfs()
+    for u, v in enumerate(views):
+        d = bs.fetch(u)
+        a, b = v.log_prob(), d.log_prob()
+        assert a.shape == b.shape == (bs.num_frames(u), tid2pdf_n if bs.num_frames(u) else 0)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        if bs.num_frames(u):
+            assert v.is_last_frame(bs.num_frames(u) - 1) and not v.is_last_frame(-1)
+        d.destroy()
+        v.destroy()                                  # a view: nothing is freed
+    # second round with other audio: the same arena now holds the new results
+    waves2 = [synth.utterance(90 + u, 0.7) for u in range(3)]
+    bs.set_waves(waves2)
+    bs.score(0.1, sync=True)
+    views2 = bs.fetch_all()
+    for u, v in enumerate(views2):
+        d = bs.fetch(u)
+        assert np.array_equal(v.log_prob().view(np.uint32), d.log_prob().view(np.uint32))
+        d.destroy()

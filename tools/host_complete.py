@@ -27,3 +27,33 @@ for rep in range(3):
              frames / (t3 - t0), frames / (t2 - t1)), flush=True)
     for d in ds:
         d.destroy()
+
+# Page-locked arena + one transfer per batch (pk_mi355_batch_fetch_all), two batches in flight
+# so that one batch's D2H runs while the other is being scored.
+print("-- fetch_all, two batches in flight", flush=True)
+pair = [bs, pk.BatchScorer(am, synth.global_cmvn_stats(), B, sum(len(w) for w in waves))]
+w16 = [w.astype(np.int16) for w in waves]
+for s in pair:                                   # first use allocates the arena: untimed
+    s.set_waves_i16(w16); s.score(0.1, sync=True); s.fetch_all()
+t0 = time.perf_counter()
+pair[0].fetch_all()
+dt = time.perf_counter() - t0
+print("one fetch_all alone (idle GPU): %.1f ms = %.1f GB/s" % (dt * 1e3, pair[0].total_frames() * 3000 * 4 / dt / 1e9), flush=True)
+for rep in range(3):
+    n_batches = 16
+    t0 = time.perf_counter()
+    pending = [None, None]
+    done = 0
+    for k in range(n_batches + 2):
+        s = pair[k % 2]
+        if pending[k % 2] is not None:
+            s.synchronize()                      # this batch's log-likelihoods are on the host now
+            done += s.total_frames()
+            pending[k % 2] = None
+        if k < n_batches:
+            s.set_waves_i16(w16)                 # int16 PCM, 320 B/frame over the link
+            s.score(0.1, sync=False)
+            pending[k % 2] = s.fetch_all(sync=False)
+    dt = time.perf_counter() - t0
+    print("rep %d: %d batches, %.1f ms each -> host-complete %.3g frames/s (%.1f GB/s D2H average)"
+          % (rep, n_batches, dt / n_batches * 1e3, done / dt, done * 3000 * 4 / dt / 1e9), flush=True)
