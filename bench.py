@@ -64,6 +64,90 @@ def cpu_baseline(model_name, seconds, num_utts):
                       % (num_utts, seconds, frames, model_name, dt)}
 
 
+def cpu_baseline_all_cores(model_name, seconds, utts_per_thread):
+    """the same port with utterance-level parallelism over every host
+    core this process may use (one oracle instance per thread; the C calls release the GIL)."""
+    import threading
+    from oracle import oracle as O
+    from pocketkaldi_amd import synth
+    cores = len(os.sched_getaffinity(0))
+    layers, prior, L, R = synth.model(model_name)
+    g = synth.global_cmvn_stats()
+    waves = [synth.utterance(u, seconds) for u in range(utts_per_thread)]
+    frames = [0] * cores
+    objs = [(O.Nnet(layers), O.Fbank()) for _ in range(cores)]
+
+    def work(i):
+        nn, fb = objs[i]
+        for w in waves:
+            feats = O.cmvn(g, fb.compute(w))
+            nn.am_compute(feats, prior, L, R, 0.1)
+            frames[i] += feats.shape[0]
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": sum(frames) / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d threads x %d utterances x %.0f s (%d frames), model %s, whole path, %.1f s wall"
+                      % (cores, utts_per_thread, seconds, sum(frames), model_name, dt)}
+
+
+def other_configs(pk, synth, torch, steps):
+    """BASELINE.json configs[1] (one utterance, model S) and configs[4] (wide model on the fp16
+    matrix cores), device-complete like the headline; supplementary lines, N = 1 only."""
+    out = {}
+    g = synth.global_cmvn_stats()
+    # configs[1]: latency of ONE 10 s utterance through the whole path
+    layers, prior, L, R = synth.model("S")
+    am = pk.AcousticModel(layers, prior, L, R)
+    w = synth.utterance(0, 10.0)
+    pcm = torch.from_numpy(w).cuda()
+    bs = pk.BatchScorer(am, g, 1, len(w))
+    bs.set_waves_device(pcm.data_ptr(), [len(w)], keep_alive=pcm)
+    for _ in range(10):
+        bs.score(0.1, sync=True)
+    n = 200
+    t0 = time.perf_counter()
+    for _ in range(n):
+        bs.score(0.1, sync=True)          # synchronous: this is a latency, not a pipelined rate
+    dt = (time.perf_counter() - t0) / n
+    out["configs[1] one utterance, model S, f32"] = {
+        "ms_per_utterance": dt * 1e3, "frames_per_s": bs.total_frames() / dt, "frames": bs.total_frames(),
+        "gemm_tflops": am.flops_per_frame() * bs.total_frames() / dt / 1e12,
+        "note": "launch/latency-bound (8 x 8 tiles of 128 on 256 CUs -> 64 x 64 tiles); weights 26.7 MB re-read per utterance"}
+    bs.close()
+    # configs[4]: wide model, fp16 matrix cores (split-fp16 operands), 256 utterances
+    layers, prior, L, R = synth.model("W")
+    amw = pk.AcousticModel(layers, prior, L, R, precision="f16x3")
+    B = 256
+    waves = [synth.utterance(u, 10.0) for u in range(B)]
+    ns = [len(x) for x in waves]
+    pcm = torch.from_numpy(np.concatenate(waves)).cuda()
+    bw = pk.BatchScorer(amw, g, B, int(sum(ns)))
+    bw.set_waves_device(pcm.data_ptr(), ns, keep_alive=pcm)
+    bw.score(0.1, sync=True)
+    bw.enable_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        bw.score(0.1, sync=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    gm = bw.timing()["gemm"][0]
+    alg = amw.flops_per_frame() * bw.total_frames() / (gm * 1e-3) / 1e12
+    out["configs[4] wide model 6 x 2048 -> 8000, f16x3, 256 utterances"] = {
+        "frames_per_s": bw.total_frames() / dt, "ms_per_step": dt * 1e3,
+        "gemm_tflops_algorithmic": alg, "gemm_tflops_mfma_issued": 3.0 * alg,
+        "fp16_mfma_peak": FP16_MFMA_PEAK_TFLOPS, "frac_of_fp16_peak_issued": 3.0 * alg / FP16_MFMA_PEAK_TFLOPS,
+        "stage_ms_per_step": {k: bw.timing()[k][0] for k in pk.KINDS}}
+    bw.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +164,8 @@ def main():
     ap.add_argument("--no-other-precision", action="store_true",
                     help="skip the supplementary run in the other precision mode")
     ap.add_argument("--cpu-utts", type=int, default=128, help="utterances in the CPU-baseline sample (~15 s of CPU)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the supplementary BASELINE configs[1] / configs[4] lines (N = 1 only)")
     args = ap.parse_args()
 
     import torch
@@ -228,8 +314,12 @@ def main():
             rows = frames_per_step + 10 * args.batch
             out["roofline"]["algorithmic_bytes_per_launch"] = (
                 sum(4.0 * (rows * kin + k * n + rows * n) for kin, k, n in lay) / gemm_launches)
+        if world == 1 and not args.no_other_configs:
+            bs.close()
+            out["other_configs"] = other_configs(pk, synth, torch, max(2, min(args.steps, 3)))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, args.seconds, args.cpu_utts)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.model, args.seconds, 64)
         print(json.dumps(out), flush=True)
     pkdist.barrier()
     bs.close()

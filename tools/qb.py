@@ -17,7 +17,7 @@ for v in vals:
     env = dict(os.environ)
     if sweep:
         env[name] = v
-    p = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--no-other-precision"] + args, env=env,
+    p = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--no-other-precision", "--no-other-configs"] + args, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
         d = json.loads(p.stdout.strip().splitlines()[-1])
