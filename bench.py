@@ -65,12 +65,13 @@ def cpu_baseline(model_name, seconds, num_utts):
 
 
 def cpu_baseline_all_cores(model_name, seconds, utts_per_thread):
-    """the same port with utterance-level parallelism over every host
-    core this process may use (one oracle instance per thread; the C calls release the GIL)."""
+    """the same port with utterance-level parallelism over the host cores
+    of this box's share (one oracle instance per thread; the C calls release the GIL)."""
     import threading
     from oracle import oracle as O
     from pocketkaldi_amd import synth
-    cores = len(os.sched_getaffinity(0))
+    # a 1-GPU box's CPU share is 16 cores whatever the affinity mask says
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("PK_BENCH_CPU_THREADS", "16")))
     layers, prior, L, R = synth.model(model_name)
     g = synth.global_cmvn_stats()
     waves = [synth.utterance(u, seconds) for u in range(utts_per_thread)]
@@ -319,7 +320,7 @@ def main():
             out["other_configs"] = other_configs(pk, synth, torch, max(2, min(args.steps, 3)))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, args.seconds, args.cpu_utts)
-            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.model, args.seconds, 64)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.model, args.seconds, 32)
         print(json.dumps(out), flush=True)
     pkdist.barrier()
     bs.close()
