@@ -129,6 +129,14 @@ int pk_mi355_am_read(pk_mi355_am_t *am, const char *nnet_path, const char *prior
                      const char *tid2pdf_path, int left_context, int right_context,
                      int num_pdfs);
 
+/* pk_load's share of this path (pocketkaldi.cc:72-144): read the reference's "key = value" model
+ * file (configuration.cc:16-72: '#' comments, keys case-insensitive, relative paths resolved
+ * against the file's directory) and load what acoustic scoring needs -- cmvn_stats (VEC0 of 40
+ * sums + count, into cmvn_stats41) and the AcousticModel keys nnet, prior, left_context,
+ * right_context, num_pdfs, tid2pdf (am.cc:22-62).  The decoder's keys (fst, symbol_table) are
+ * not touched.  precision: PK_MI355_PRECISION_*.  On success *am_out is a finalized model.     */
+int pk_mi355_load(const char *config_path, int precision, pk_mi355_am_t **am_out, float *cmvn_stats41);
+
 int pk_mi355_am_num_pdfs(const pk_mi355_am_t *am);      /* am.h:38 */
 int pk_mi355_am_input_dim(const pk_mi355_am_t *am);     /* spliced width */
 int pk_mi355_am_transition_to_pdf(const pk_mi355_am_t *am, int trans_id); /* am.h:30-32 */

@@ -2,6 +2,7 @@
 // the layer executor, the batched scorer and the reference-compatible
 // pk_decodable_* functions.  Host C++ over the HIP runtime; no CPU compute path.
 #include <hip/hip_runtime.h>
+#include <ctype.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -776,6 +777,112 @@ int pk_mi355_am_read(pk_mi355_am_t *am, const char *nnet_path, const char *prior
     return Fail(PK_MI355_E_INVALID, "prior has %d entries, num_pdfs = %d", (int)prior.size(), num_pdfs);
   return pk_mi355_am_finalize(am, prior.data(), num_pdfs, left_context, right_context,
                               tid.empty() ? nullptr : tid.data(), (int)tid.size());
+}
+
+// ---- pk_load's share of this path (pocketkaldi.cc:72-144): the key = value model file.
+namespace {
+
+std::string TrimWs(const std::string &s) {
+  size_t a = 0, b = s.size();
+  while (a < b && isspace((unsigned char)s[a])) ++a;
+  while (b > a && isspace((unsigned char)s[b - 1])) --b;
+  return s.substr(a, b - a);
+}
+
+// configuration.cc:16-55: '#' comments and blank lines skipped, exactly one '=' per line,
+// keys lower-cased, empty values rejected.
+struct ConfigFile {
+  std::string filename;
+  std::vector<std::pair<std::string, std::string>> table;
+
+  int Read(const char *path) {
+    filename = path;
+    FILE *f = fopen(path, "r");
+    if (!f) return Fail(PK_MI355_E_IO, "cannot open %s", path);
+    std::string text;
+    char buf[4096];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof(buf), f)) > 0) text.append(buf, n);
+    fclose(f);
+    size_t pos = 0;
+    while (pos < text.size()) {
+      size_t e = text.find('\n', pos);
+      if (e == std::string::npos) e = text.size();
+      const std::string line = TrimWs(text.substr(pos, e - pos));
+      pos = e + 1;
+      if (line.empty() || line[0] == '#') continue;
+      const size_t eq = line.find('=');
+      if (eq == std::string::npos || line.find('=', eq + 1) != std::string::npos)
+        return Fail(PK_MI355_E_IO, "Unexpected line in %s: %s", path, line.c_str());
+      std::string key = TrimWs(line.substr(0, eq));
+      const std::string value = TrimWs(line.substr(eq + 1));
+      for (auto &c : key) c = (char)tolower((unsigned char)c);
+      if (value.empty()) return Fail(PK_MI355_E_IO, "Value cound not be empty: %s: %s", path, line.c_str());
+      bool found = false;
+      for (auto &kv : table)
+        if (kv.first == key) { kv.second = value; found = true; }
+      if (!found) table.emplace_back(key, value);
+    }
+    return 0;
+  }
+  const std::string *Find(const char *key) const {
+    for (const auto &kv : table)
+      if (kv.first == key) return &kv.second;
+    return nullptr;
+  }
+  // configuration.cc:57-72: relative paths are relative to the directory of the file
+  int Path(const char *key, std::string *out) const {
+    const std::string *v = Find(key);
+    if (!v) return Fail(PK_MI355_E_IO, "Unable to find key '%s' in %s", key, filename.c_str());
+    const size_t slash = filename.rfind('/');
+    *out = ((*v)[0] == '/' || slash == std::string::npos) ? *v : filename.substr(0, slash + 1) + *v;
+    return 0;
+  }
+  int Integer(const char *key, int *out) const {
+    const std::string *v = Find(key);
+    if (!v) return Fail(PK_MI355_E_IO, "Unable to find key '%s' in %s", key, filename.c_str());
+    char *end = nullptr;
+    const long x = strtol(v->c_str(), &end, 10);
+    if (end == v->c_str()) return Fail(PK_MI355_E_IO, "key '%s' in %s is not an integer: %s", key, filename.c_str(), v->c_str());
+    *out = (int)x;
+    return 0;
+  }
+};
+
+}  // namespace
+
+int pk_mi355_load(const char *config_path, int precision, pk_mi355_am_t **am_out, float *cmvn_stats41) {
+  if (!config_path || !am_out || !cmvn_stats41) return Fail(PK_MI355_E_INVALID, "null argument");
+  *am_out = nullptr;
+  ConfigFile conf;
+  int rc = conf.Read(config_path);
+  if (rc) return rc;
+  // CMVN global statistics, pocketkaldi.cc:101-116: VEC0 of 40 sums + the frame count
+  std::string cmvn_path, nnet, prior, tid2pdf;
+  if ((rc = conf.Path("cmvn_stats", &cmvn_path))) return rc;
+  FileBuf cf;
+  std::vector<float> stats;
+  if ((rc = cf.Open(cmvn_path.c_str())) || (rc = cf.Vec(&stats))) return rc;
+  if ((int)stats.size() != kNumBins + 1)
+    return Fail(PK_MI355_E_IO, "cmvn_stats in %s has %d entries, %d expected", cmvn_path.c_str(), (int)stats.size(), kNumBins + 1);
+  // AcousticModel::Read, am.cc:22-62 (a missing left_context is not an error there either)
+  int left = 0, right = 0, num_pdfs = 0;
+  if ((rc = conf.Path("nnet", &nnet)) || (rc = conf.Path("prior", &prior))) return rc;
+  if (conf.Find("left_context") && (rc = conf.Integer("left_context", &left))) return rc;
+  if ((rc = conf.Integer("right_context", &right)) || (rc = conf.Integer("num_pdfs", &num_pdfs)) ||
+      (rc = conf.Path("tid2pdf", &tid2pdf)))
+    return rc;
+  if (left < 0 || right < 0) return Fail(PK_MI355_E_INVALID, "negative context in %s", config_path);
+  pk_mi355_am_t *am = pk_mi355_am_create();
+  if (!am) return PK_MI355_E_DEVICE;
+  if ((rc = pk_mi355_am_set_precision(am, precision)) ||
+      (rc = pk_mi355_am_read(am, nnet.c_str(), prior.c_str(), tid2pdf.c_str(), left, right, num_pdfs))) {
+    pk_mi355_am_destroy(am);
+    return rc;
+  }
+  memcpy(cmvn_stats41, stats.data(), sizeof(float) * (kNumBins + 1));
+  *am_out = am;
+  return 0;
 }
 
 int pk_mi355_am_num_pdfs(const pk_mi355_am_t *am) { return am ? am->num_pdfs : 0; }

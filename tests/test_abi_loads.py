@@ -108,3 +108,38 @@ def test_wav_reader_rejects_what_the_reference_rejects(tmp_path):
                b"data" + struct.pack("<i", len(payload)))
         w = pk.read_wav(write("pcm%d.wav" % bits, hdr + payload))
         assert list(w[:2]) == vals and w.shape == (n,)
+
+
+def test_model_config_errors_without_gpu(tmp_path):
+    """pk_mi355_load parses the reference's key = value model file (configuration.cc:16-72) before
+    anything touches the device: the reference's error cases are reported the same way."""
+    import struct
+    import pocketkaldi_amd as pk
+
+    def load(text):
+        p = tmp_path / "model.conf"
+        p.write_text(text)
+        return pk.AcousticModel.load(str(p))
+
+    with pytest.raises(pk.PkError, match="cannot open"):
+        pk.AcousticModel.load(str(tmp_path / "absent.conf"))
+    with pytest.raises(pk.PkError, match="Unexpected line"):
+        load("# comment\nnnet am.nnet\n")
+    with pytest.raises(pk.PkError, match="Unexpected line"):
+        load("nnet = a = b\n")
+    with pytest.raises(pk.PkError, match="empty"):
+        load("nnet =   \n")
+    with pytest.raises(pk.PkError, match="Unable to find key 'cmvn_stats'"):
+        load("\n  # only a comment\nNNET = am.nnet\n")
+    with pytest.raises(pk.PkError, match="cannot open .*/stats.bin"):
+        load("cmvn_stats = stats.bin\n")            # relative to the config's directory
+    with open(tmp_path / "stats.bin", "wb") as f:   # 3 entries instead of 41
+        f.write(b"VEC0" + struct.pack("<ii", 16, 3) + struct.pack("<3f", 1, 2, 3))
+    with pytest.raises(pk.PkError, match="41 expected"):
+        load("cmvn_stats = stats.bin\n")
+    with open(tmp_path / "stats.bin", "wb") as f:
+        f.write(b"VEC0" + struct.pack("<ii", 41 * 4 + 4, 41) + struct.pack("<41f", *range(41)))
+    with pytest.raises(pk.PkError, match="Unable to find key 'nnet'"):
+        load("Cmvn_Stats = stats.bin\n")            # keys are case-insensitive
+    with pytest.raises(pk.PkError, match="Unable to find key 'right_context'"):
+        load("cmvn_stats = stats.bin\nnnet = a\nprior = b\nleft_context = 5\n")

@@ -316,6 +316,19 @@ def test_model_files_roundtrip(tmp_path):
                       O.Nnet(layers).propagate(O.splice(feats, L, R)))
     with pytest.raises(pk.PkError):
         pk.AcousticModel.read(str(tmp_path / "am.prior"), str(tmp_path / "am.prior"), None, L, R, 50)
+    # the same files through the reference's model config (pk_load, pocketkaldi.cc:72-144):
+    # relative paths, mixed-case keys, comments, decoder keys ignored
+    g = synth.global_cmvn_stats()
+    with open(tmp_path / "cmvn.bin", "wb") as f:
+        vec(f, g.tolist())
+    (tmp_path / "pocketkaldi.conf").write_text(
+        "# model\nfst = HCLG.pfst\nsymbol_table = words.bin\ncmvn_stats = cmvn.bin\n"
+        "NNET = am.nnet\nprior=am.prior\n  tid2pdf = %s \nleft_context = %d\nright_context = %d\nnum_pdfs = 50\n"
+        % (tmp_path / "tid2pdf.bin", L, R))
+    am_conf, stats = pk.AcousticModel.load(str(tmp_path / "pocketkaldi.conf"))
+    assert bits_equal(stats, g)
+    assert bits_equal(pk.Decodable(am_conf, 0.1, feats).log_prob(), pk.Decodable(am_mem, 0.1, feats).log_prob())
+    assert am_conf.transition_id_to_pdf_id(3) == tid2pdf[3] and am_conf.num_pdfs() == 50
 
 
 # ------------------------------------------------------------------ f16x3 precision mode
