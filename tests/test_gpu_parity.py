@@ -271,14 +271,18 @@ def test_chunking_is_invisible(monkeypatch):
     waves = [synth.utterance(40 + i, seconds=2.5) for i in range(6)]
     am = pk.AcousticModel(layers, prior, L, R)
     outs = []
-    for chunk in ("128", "8192"):
+    for chunk, lanes in (("128", "1"), ("8192", "1"), ("256", "2")):   # lanes = 2: odd chunks on a second stream
         monkeypatch.setenv("PK_MI355_CHUNK", chunk)
+        monkeypatch.setenv("PK_MI355_LANES", lanes)
         bs = pk.BatchScorer(am, g, len(waves), sum(len(w) for w in waves))
         bs.set_waves(waves)
-        bs.score(0.1)
+        for _ in range(2):                      # twice: the second pass must wait for both lanes of the first
+            bs.score(0.1, sync=False)
+        bs.synchronize()
         outs.append([bs.fetch(u).log_prob() for u in range(len(waves))])
-    for a, b in zip(*outs):
-        assert bits_equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert bits_equal(a, b)
 
 
 def test_model_files_roundtrip(tmp_path):
