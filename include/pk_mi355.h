@@ -219,6 +219,9 @@ int pk_mi355_batch_fetch_all(pk_mi355_batch_t *b, pk_decodable_t *out, int num_o
  * copied to host as [T][40].                                                     */
 int pk_mi355_batch_fetch_fbank(pk_mi355_batch_t *b, int utt, float *out);
 int pk_mi355_batch_fetch_cmvn(pk_mi355_batch_t *b, int utt, float *out);
+/* Parity-test hook: the front-end's logf (fbank.cc:244-245 -> vector.cc:334-339 -> libm logf,
+ * restated for the device in csrc/pk_logf.h) on n host floats (positive normal, +inf or NaN).  */
+int pk_mi355_test_logf(const float *x, int n, float *out);
 
 /* Device-side pk_decodable_loglikelihood (decodable.cc:24-31) for a GPU-resident consumer
  * (decoder.cc:252-279 evaluates one (frame, transition-id) pair per arc): n pairs in

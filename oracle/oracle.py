@@ -53,6 +53,7 @@ def lib():
         L.pko_fbank_frame.argtypes = [C.c_void_p, _f32p, _f32p, C.c_void_p]
         L.pko_cmvn.argtypes = [_f32p, _f32p, C.c_int, _f32p]
         L.pko_splice.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]
+        L.pko_logf_array.argtypes = [_f32p, C.c_int, _f32p]
         for name in ("pko_sgemm", "pko_sgemm_naive"):
             getattr(L, name).argtypes = [C.c_int, C.c_int, C.c_int, _f32p, C.c_int, _f32p,
                                          C.c_int, _f32p, C.c_int]
@@ -155,6 +156,14 @@ def cmvn(global_stats, raw):
     out = np.zeros_like(raw)
     if raw.shape[0]:
         lib().pko_cmvn(g, raw, raw.shape[0], out)
+    return out
+
+
+def logf(x):
+    """libm logf per element (vector.cc:334-339)."""
+    x = np.ascontiguousarray(x, dtype=np.float32).ravel()
+    out = np.empty_like(x)
+    lib().pko_logf_array(x, x.shape[0], out)
     return out
 
 

@@ -398,6 +398,10 @@ void pko_cmvn(const float *g, const float *raw, int T, float *out) {
 /* splice                                                                     */
 /* ------------------------------------------------------------------------- */
 
+void pko_logf_array(const float *x, int n, float *out) {
+  for (int i = 0; i < n; ++i) out[i] = logf(x[i]);   /* vector.cc:336-338 */
+}
+
 void pko_splice(const float *feats, int T, int dim, int left, int right, float *out) {
   int width = (left + right + 1) * dim;           /* am.cc:65-88 */
   for (int t = 0; t < T; ++t) {

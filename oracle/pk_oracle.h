@@ -89,6 +89,9 @@ void pko_cmvn(const float *global_stats41, const float *raw, int T, float *out);
 /* ---- splice (am.cc:65-88) ---- */
 void pko_splice(const float *feats, int T, int dim, int left, int right, float *out);
 
+/* vector.cc:334-339 ApplyLog: libm's logf, element by element (what the reference calls). */
+void pko_logf_array(const float *x, int n, float *out);
+
 /* ---- SGEMM with the reference's accumulation order (gemm.cc, gemm_haswell.cc) ----
  * C[m][n] (row-major, ldc) = A[m][k] (row-major, lda) * B[k][n] (row-major, ldb)
  * Per element: k ascending fused-multiply-add chain from 0 inside each chunk of

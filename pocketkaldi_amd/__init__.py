@@ -61,7 +61,7 @@ EXPORTS = [
     "pk_mi355_batch_set_waves", "pk_mi355_batch_set_waves_i16", "pk_mi355_batch_set_waves_device",
     "pk_mi355_batch_score", "pk_mi355_batch_synchronize", "pk_mi355_batch_num_utts",
     "pk_mi355_batch_num_frames", "pk_mi355_batch_total_frames", "pk_mi355_batch_loglik_device",
-    "pk_mi355_batch_fetch", "pk_mi355_batch_fetch_all", "pk_mi355_batch_fetch_fbank", "pk_mi355_batch_fetch_cmvn",
+    "pk_mi355_batch_fetch", "pk_mi355_batch_fetch_all", "pk_mi355_batch_fetch_fbank", "pk_mi355_batch_fetch_cmvn", "pk_mi355_test_logf",
     "pk_mi355_batch_gather_loglik", "pk_mi355_device_malloc", "pk_mi355_device_free", "pk_mi355_memcpy",
     "pk_mi355_host_malloc", "pk_mi355_host_free",
     "pk_mi355_batch_stream", "pk_mi355_batch_enable_timing", "pk_mi355_batch_get_timing",
@@ -144,6 +144,7 @@ def lib():
     L.pk_mi355_batch_fetch_all.argtypes = [C.c_void_p, C.POINTER(pk_decodable_t), C.c_int, C.c_int]
     L.pk_mi355_batch_fetch_fbank.argtypes = [C.c_void_p, C.c_int, f32p]
     L.pk_mi355_batch_fetch_cmvn.argtypes = [C.c_void_p, C.c_int, f32p]
+    L.pk_mi355_test_logf.argtypes = [f32p, C.c_int, f32p]
     L.pk_mi355_batch_gather_loglik.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.pk_mi355_device_malloc.restype = C.c_void_p
     L.pk_mi355_device_malloc.argtypes = [C.c_size_t]
@@ -345,6 +346,14 @@ class AcousticModel:
         m_out = pk_matrix_t(0, 0, None)
         _check(lib().pk_mi355_nnet_propagate(self._h, C.byref(m_in), C.byref(m_out)))
         return _take_matrix(m_out)
+
+
+def device_logf(x):
+    """The front-end kernel's logf on an array (parity-test hook)."""
+    x = _f32(x).ravel()
+    out = np.empty_like(x)
+    _check(lib().pk_mi355_test_logf(_fp(x), x.shape[0], _fp(out)))
+    return out
 
 
 class _Pinned:

@@ -1337,6 +1337,28 @@ int pk_mi355_batch_fetch_all(pk_mi355_batch_t *b, pk_decodable_t *out, int num_o
   return 0;
 }
 
+int pk_mi355_test_logf(const float *x, int n, float *out) {
+  if (!x || !out || n < 0) return Fail(PK_MI355_E_INVALID, "bad argument");
+  int rc = UseDevice(g_device);
+  if (rc || n == 0) return rc;
+  FrontendTables host;
+  if (BuildFrontendTables(&host)) return Fail(PK_MI355_E_INVALID, "front-end table construction failed");
+  FrontendTables *d_tab = nullptr;
+  float *d_x = nullptr, *d_y = nullptr;
+  hipError_t e = hipMalloc(&d_tab, sizeof(host));
+  if (e == hipSuccess) e = hipMalloc(&d_x, sizeof(float) * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc(&d_y, sizeof(float) * (size_t)n);
+  if (e == hipSuccess) e = hipMemcpy(d_tab, &host, sizeof(host), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_x, x, sizeof(float) * (size_t)n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    LaunchLogfTest(d_x, n, d_tab, d_y, nullptr);
+    e = hipMemcpy(out, d_y, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost);
+  }
+  hipFree(d_tab); hipFree(d_x); hipFree(d_y);
+  if (e != hipSuccess) return Fail(PK_MI355_E_DEVICE, "test_logf: %s", hipGetErrorString(e));
+  return 0;
+}
+
 int pk_mi355_batch_fetch_fbank(pk_mi355_batch_t *b, int utt, float *out) {
   if (!b || !out || utt < 0 || utt >= b->num_utts) return Fail(PK_MI355_E_INVALID, "bad utterance index");
   if (!b->scored) return Fail(PK_MI355_E_STATE, "batch not scored");

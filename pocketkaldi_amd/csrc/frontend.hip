@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include "pk_kernels.h"
+#include "pk_logf.h"
 
 #pragma clang fp contract(off)
 
@@ -83,6 +84,7 @@ __device__ __forceinline__ void LButterfly(f32x2 *z, int base, int n, const floa
 // kernel is latency-bound: a table value fetched from L2 inside every FFT pass costs
 // more than the butterfly it feeds).  Mel weights are packed back to back.
 struct LdsTables {
+  double logf_tab[kLogfTableDoubles];
   float window[kFrameLength];
   float tw[kTwFloats];
   float post_re[kFftCplx / 2 + 1];
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
   // ---- tables: global -> LDS, once per workgroup
   {
     const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < kLogfTableDoubles; i += nt) tab.logf_tab[i] = gtab->logf_tab[i];
     for (int i = tid; i < kFrameLength; i += nt) tab.window[i] = gtab->window[i];
     for (int i = tid; i < kTwFloats; i += nt) tab.tw[i] = gtab->tw[i];
     for (int i = tid; i <= kFftCplx / 2; i += nt) { tab.post_re[i] = gtab->post_re[i]; tab.post_im[i] = gtab->post_im[i]; }
@@ -298,14 +301,14 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
     WaveSync();
 
     // ---- fbank.cc:165-184 (sequential float dot per bin, vector.cc:252-262),
-    // floor FLT_EPSILON and log (fbank.cc:244-245)
+    // floor FLT_EPSILON and log (fbank.cc:244-245; the C library's logf, pk_logf.h)
     if (lane < kNumBins) {
       const int off = tab.mel_off[lane], len = tab.mel_len[lane];
       const float *mw = tab.mel_w + tab.mel_base[lane];
       float e = 0.0f;
       for (int j = 0; j < len; ++j) e += mw[j] * s_pow[off + j];
       if (e < 1.1920928955078125e-07f) e = 1.1920928955078125e-07f;
-      out0[(int64_t)t * kNumBins + lane] = static_cast<float>(log(static_cast<double>(e)));
+      out0[(int64_t)t * kNumBins + lane] = LogfRestated(e, tab.logf_tab);
     }
     WaveSync();
 #pragma unroll
@@ -443,6 +446,18 @@ __global__ void PadTransposeKernel(const float *__restrict__ feats, int T, int d
 }
 
 }  // namespace
+
+// Parity-test hook: LogfRestated on arbitrary inputs.
+__global__ void LogfTestKernel(const float *__restrict__ x, int n, const FrontendTables *__restrict__ gtab,
+                               float *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = LogfRestated(x[i], gtab->logf_tab);
+}
+
+void LaunchLogfTest(const float *x, int n, const FrontendTables *d_tables, float *out, hipStream_t stream) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(LogfTestKernel, dim3((n + 255) / 256), dim3(256), 0, stream, x, n, d_tables, out);
+}
 
 void LaunchFbank(const float *wave_f32, const int16_t *wave_i16, const UttLayout &utts,
                  int num_utts, int max_frames, const FrontendTables *d_tables, float *raw,

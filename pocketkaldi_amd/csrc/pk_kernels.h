@@ -25,6 +25,9 @@ void LaunchFbank(const float *wave_f32, const int16_t *wave_i16, const UttLayout
                  int num_utts, int max_frames, const FrontendTables *d_tables, float *raw,
                  hipStream_t stream);
 
+// parity-test hook: the kernel's logf (pk_logf.h) on n device floats
+void LaunchLogfTest(const float *x, int n, const FrontendTables *d_tables, float *out, hipStream_t stream);
+
 // cmvn.cc:103-115 for a batch: raw [sum T][40] -> feature-major, edge-padded
 // Yt[40][ldy]: utterance u occupies columns pad_base[u] .. pad_base[u]+T+left+right-1,
 // its frame t at column pad_base[u]+left+t, the first/last frame replicated into

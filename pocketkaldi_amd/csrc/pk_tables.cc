@@ -2,6 +2,7 @@
 // Compile: g++ -O2 -ffp-contract=off (no -march): float expressions must round
 // exactly where the reference's do.  See pk_tables.h for what each table is.
 #include "pk_tables.h"
+#include "pk_logf.h"
 
 #include <math.h>
 #include <string.h>
@@ -40,6 +41,8 @@ float MelScale(float freq) {  // fbank.h:30-32
 
 int BuildFrontendTables(FrontendTables *t) {
   memset(t, 0, sizeof(*t));
+  static const double logf_tab[kLogfTableDoubles] = PK_LOGF_TABLE_INIT;
+  memcpy(t->logf_tab, logf_tab, sizeof(logf_tab));
 
   // ---- Hamming window, fbank.cc:249-256 (float angle step, float cos, the
   // 0.54 - 0.46 * c expression in double, one rounding to float)

@@ -37,6 +37,7 @@ constexpr int kMelMaxLen = 64;         // longest triangle (checked at build tim
 constexpr int kMelPacked = 640;        // all triangles back to back (sum of lengths, checked)
 
 struct FrontendTables {
+  double logf_tab[32];                 // pk_logf.h: 16 x (1/c, log c) of the C library's logf
   float window[kFrameLength];
   // FFT
   int32_t pass_start[kNumPasses + 1];
