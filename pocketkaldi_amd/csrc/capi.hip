@@ -779,6 +779,8 @@ int pk_mi355_am_read(pk_mi355_am_t *am, const char *nnet_path, const char *prior
                               tid.empty() ? nullptr : tid.data(), (int)tid.size());
 }
 
+}  // extern "C"
+
 // ---- pk_load's share of this path (pocketkaldi.cc:72-144): the key = value model file.
 namespace {
 
@@ -850,6 +852,8 @@ struct ConfigFile {
 };
 
 }  // namespace
+
+extern "C" {
 
 int pk_mi355_load(const char *config_path, int precision, pk_mi355_am_t **am_out, float *cmvn_stats41) {
   if (!config_path || !am_out || !cmvn_stats41) return Fail(PK_MI355_E_INVALID, "null argument");

@@ -316,120 +316,136 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
   }
 }
 
-// One wavefront per utterance, one lane per feature; lanes walk the frames in order
-// because the running window sum is rounded to float every frame (cmvn.cc:66-70).  The
-// window count is min(t + 1, 600), so the smoothing weight and the 1/count scale come
-// from the host-built CmvnTables; the serial chain per frame is one fp64 add (two once
-// the window slides), one narrowing, two float multiply-adds.
-// Memory never touches the chain: frames move HBM -> LDS in tiles of 64 (contiguous
-// 10 KiB, LDS-DMA, the next tile in flight while the current one is walked), results go
-// LDS -> HBM as 40 rows of 64 consecutive frames (256-byte stores).
+// One workgroup of four wavefronts per utterance.  The running window sum is rounded to float
+// every frame (cmvn.cc:66-70), so ONE wavefront walks the frames in order, one lane per
+// feature, and does nothing but that chain -- widen, one fp64 add (two once the window
+// slides), narrow -- leaving S_t in LDS.  Everything else is parallel over frames and belongs
+// to the other waves: one moves frames HBM -> LDS by LDS-DMA a tile (64 frames, 10 KiB) ahead,
+// two turn (x_t, S_t) of the previous tile into y_t (lane = frame) and store rows of 64
+// consecutive frames (256 bytes) into the feature-major operand of the first affine layer.
+// The window count is min(t + 1, 600), so the smoothing weight and the 1/count scale come
+// from the host-built CmvnTables.  One raw s_barrier per tile.
 constexpr int kCmvnTile = 64;                                   // frames per tile
 constexpr int kCmvnTileFloats = kCmvnTile * kNumBins;           // 2560 floats = 10 KiB
-constexpr int kCmvnOutLd = kCmvnTile + 1;                       // bank-conflict padding
+constexpr int kCmvnWaves = 4;                                   // chain, two writers, loader
 
-__global__ __launch_bounds__(kWave) void CmvnKernel(const float *__restrict__ raw, UttLayout utts,
-                                                    const float *__restrict__ g,
-                                                    const CmvnTables *__restrict__ tab, int left,
-                                                    int right, float *__restrict__ yt,
-                                                    int64_t ldy) {
+__global__ __launch_bounds__(kWave * kCmvnWaves) void CmvnKernel(
+    const float *__restrict__ raw, UttLayout utts, const float *__restrict__ g,
+    const CmvnTables *__restrict__ tab, int left, int right, float *__restrict__ yt, int64_t ldy) {
   // ONE LDS array, carved by hand: with several __shared__ objects hipcc waits for the
-  // in-flight LDS-DMA of the next tile before every LDS read of the current one
-  __shared__ __attribute__((aligned(16))) float lds[4 * kCmvnTileFloats + kNumBins * kCmvnOutLd + 2 * kCmvnWindow];
-  float *s_in = lds;                                  // [2][tile]: x[t][d]
-  float *s_old = lds + 2 * kCmvnTileFloats;           // [2][tile]: x[t - 600][d]
-  float *s_out = lds + 4 * kCmvnTileFloats;           // y[d][t]
-  float *s_alpha = s_out + kNumBins * kCmvnOutLd, *s_nscale = s_alpha + kCmvnWindow;
+  // in-flight LDS-DMA before every LDS read
+  __shared__ __attribute__((aligned(16))) float lds[7 * kCmvnTileFloats + 2 * kCmvnWindow];
+  float *s_in = lds;                                  // [3][tile]: x[t][d]  (loading / chain / writers)
+  float *s_old = lds + 3 * kCmvnTileFloats;           // [2][tile]: x[t - 600][d]
+  float *s_sum = lds + 5 * kCmvnTileFloats;           // [2][tile]: S_t[d], the window sums after frame t
+  float *s_alpha = lds + 7 * kCmvnTileFloats, *s_nscale = s_alpha + kCmvnWindow;
 
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 chain, 1-2 writers, 3 loader
   const int utt = blockIdx.x;
   const int T = utts.num_frames[utt];
   if (T <= 0) return;
   const float *x0 = raw + utts.raw_base[utt] * kNumBins;
   float *y0 = yt + utts.pad_base[utt];
-  for (int i = lane; i < kCmvnWindow; i += kWave) { s_alpha[i] = tab->alpha[i]; s_nscale[i] = tab->neg_scale[i]; }
+  for (int i = threadIdx.x; i < kCmvnWindow; i += kWave * kCmvnWaves) { s_alpha[i] = tab->alpha[i]; s_nscale[i] = tab->neg_scale[i]; }
 
   typedef const __attribute__((address_space(1))) void *GlobalPtr;
   typedef __attribute__((address_space(3))) void *LdsPtr;
   const int ntiles = (T + kCmvnTile - 1) / kCmvnTile;
-  // tile `i` of the utterance (and of the frames leaving the window) -> LDS buffer i & 1.
+  // tile i of the utterance -> s_in[i % 3], the frames leaving the window -> s_old[i % 2].
   // 10 x 1 KiB pieces each; source clamped to the utterance (clamped values are unused).
   auto fetch = [&](int i) {
     const int64_t total = (int64_t)T * kNumBins;
+    float *din = s_in + (i % 3) * kCmvnTileFloats, *dold = s_old + (i & 1) * kCmvnTileFloats;
+    const bool slides = (i + 1) * kCmvnTile > kCmvnWindow;     // some frame of the tile has t >= 600
 #pragma unroll
     for (int p = 0; p < kCmvnTileFloats / 256; ++p) {
       int64_t e = (int64_t)i * kCmvnTileFloats + p * 256 + lane * 4;          // float index in the utterance
       int64_t ec = e + 4 <= total ? e : total - 4;
       if (ec < 0) ec = 0;
-      __builtin_amdgcn_global_load_lds((GlobalPtr)(x0 + ec), (LdsPtr)(s_in + (i & 1) * kCmvnTileFloats + p * 256), 16, 0, 0);
-      int64_t o = e - (int64_t)kCmvnWindow * kNumBins;
-      int64_t oc = o < 0 ? 0 : (o + 4 <= total ? o : total - 4);
-      if (oc < 0) oc = 0;
-      __builtin_amdgcn_global_load_lds((GlobalPtr)(x0 + oc), (LdsPtr)(s_old + (i & 1) * kCmvnTileFloats + p * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((GlobalPtr)(x0 + ec), (LdsPtr)(din + p * 256), 16, 0, 0);
+      if (slides) {
+        int64_t o = e - (int64_t)kCmvnWindow * kNumBins;
+        int64_t oc = o < 0 ? 0 : (o + 4 <= total ? o : total - 4);
+        if (oc < 0) oc = 0;
+        __builtin_amdgcn_global_load_lds((GlobalPtr)(x0 + oc), (LdsPtr)(dold + p * 256), 16, 0, 0);
+      }
     }
   };
+  auto tile_sync = [&]() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // this wave's LDS traffic is done (lgkmcnt(0))
+    __builtin_amdgcn_s_barrier();
+  };
 
-  const int d = lane < kNumBins ? lane : 0;       // lanes 40..63 shadow feature 0 and store nothing
-  const float gd = g[d];
-  float s = 0.0f;      // cached window sum of this feature
-  float y = 0.0f;
-  fetch(0);
-  for (int i = 0; i < ntiles; ++i) {
-    // tile i has landed and the stores of tile i-1 are out; then put tile i+1 in flight
+  if (role == 3) {
+    fetch(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    if (i + 1 < ntiles) fetch(i + 1);
-    const float *xin = s_in + (i & 1) * kCmvnTileFloats, *xold = s_old + (i & 1) * kCmvnTileFloats;
-    const int t0 = i * kCmvnTile;
-    const int nt = T - t0 < kCmvnTile ? T - t0 : kCmvnTile;
-    // blocks of 8 frames: all LDS operands of the block are fetched first (they do not
-    // depend on the recurrence), so the serial chain is arithmetic only
-    constexpr int kBlk = 8;
-    for (int u0 = 0; u0 < nt; u0 += kBlk) {
-      float xs[kBlk], xo[kBlk], al[kBlk], ns[kBlk];
-#pragma unroll
-      for (int v = 0; v < kBlk; ++v) {
-        const int u = u0 + v < kCmvnTile ? u0 + v : kCmvnTile - 1;
-        const int t = t0 + u;
-        const int tt = t < kCmvnWindow ? t : kCmvnWindow - 1;
-        xs[v] = xin[u * kNumBins + d];
-        xo[v] = xold[u * kNumBins + d];
-        al[v] = s_alpha[tt];
-        ns[v] = s_nscale[tt];
+  }
+  tile_sync();
+
+  float s = 0.0f;                                  // chain wave: cached window sum of feature `lane`
+  const int d = lane < kNumBins ? lane : 0;       // lanes 40..63 of the chain wave shadow feature 0
+  for (int i = 0; i <= ntiles; ++i) {
+    if (role == 3) {
+      if (i + 1 < ntiles) {
+        fetch(i + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+    } else if (role == 0) {
+      if (i < ntiles) {
+        const float *xin = s_in + (i % 3) * kCmvnTileFloats, *xold = s_old + (i & 1) * kCmvnTileFloats;
+        float *sum = s_sum + (i & 1) * kCmvnTileFloats;
+        const int t0 = i * kCmvnTile;
+        const int nt = T - t0 < kCmvnTile ? T - t0 : kCmvnTile;
+        // blocks of 8 frames: the LDS operands of a block are fetched first (they do not
+        // depend on the recurrence), so the serial chain is arithmetic only
+        constexpr int kBlk = 8;
+        for (int u0 = 0; u0 < nt; u0 += kBlk) {
+          float xs[kBlk], xo[kBlk];
 #pragma unroll
-      for (int v = 0; v < kBlk; ++v) {
-        const int u = u0 + v, t = t0 + u;
-        if (u < nt) {
-          const float x = xs[v];
-          double acc = s;                                 // cmvn.cc:44-52
-          acc += x;
-          if (t >= kCmvnWindow) acc += -1.0 * static_cast<double>(xo[v]);   // cmvn.cc:58-64
-          s = static_cast<float>(acc);                    // cmvn.cc:66-70
-          float st = s;
-          if (t + 1 < kCmvnWindow) st += al[v] * gd;      // cmvn.cc:73-92 (count < window)
-          y = x;
-          y += ns[v] * st;                                // cmvn.cc:94-101
-          s_out[d * kCmvnOutLd + u] = y;
-          if (t == 0 && lane < kNumBins)
-            for (int p = 0; p < left; ++p) y0[(int64_t)d * ldy + p] = y;   // am.cc:73 clamp, done at write time
+          for (int v = 0; v < kBlk; ++v) {
+            const int u = u0 + v < kCmvnTile ? u0 + v : kCmvnTile - 1;
+            xs[v] = xin[u * kNumBins + d];
+            xo[v] = xold[u * kNumBins + d];
+          }
+#pragma unroll
+          for (int v = 0; v < kBlk; ++v) {
+            const int u = u0 + v, t = t0 + u;
+            if (u < nt) {
+              double acc = s;                                 // cmvn.cc:44-52
+              acc += xs[v];
+              if (t >= kCmvnWindow) acc += -1.0 * static_cast<double>(xo[v]);   // cmvn.cc:58-64
+              s = static_cast<float>(acc);                    // cmvn.cc:66-70
+              if (lane < kNumBins) sum[u * kNumBins + d] = s;
+            }
+          }
+        }
+      }
+    } else if (i >= 1) {
+      // writers: tile i - 1, lane = frame, features split between the two waves
+      const int j = i - 1;
+      const float *xin = s_in + (j % 3) * kCmvnTileFloats, *sum = s_sum + (j & 1) * kCmvnTileFloats;
+      const int t = j * kCmvnTile + lane;
+      if (t < T) {
+        const int tt = t < kCmvnWindow ? t : kCmvnWindow - 1;
+        const float al = s_alpha[tt], ns = s_nscale[tt];
+        for (int dd = role - 1; dd < kNumBins; dd += 2) {
+          const float x = xin[lane * kNumBins + dd];
+          float st = sum[lane * kNumBins + dd];
+          if (t + 1 < kCmvnWindow) st += al * g[dd];          // cmvn.cc:73-92 (count < window)
+          float y = x;
+          y += ns * st;                                       // cmvn.cc:94-101
+          float *row = y0 + (int64_t)dd * ldy;
+          row[left + t] = y;
+          if (t == 0)
+            for (int p = 0; p < left; ++p) row[p] = y;        // am.cc:73 clamp, done at write time
+          if (t == T - 1)
+            for (int p = 0; p < right; ++p) row[left + T + p] = y;   // am.cc:74
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
-    // rows of 64 consecutive frames: lane = frame
-    if (lane < nt) {
-#pragma unroll 8
-      for (int dd = 0; dd < kNumBins; ++dd)
-        y0[(int64_t)dd * ldy + left + t0 + lane] = s_out[dd * kCmvnOutLd + lane];
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
+    tile_sync();
   }
-  if (lane < kNumBins)
-    for (int p = 0; p < right; ++p) y0[(int64_t)d * ldy + left + T + p] = y;   // am.cc:74
 }
 
 __global__ void PadTransposeKernel(const float *__restrict__ feats, int T, int dim, int left,
@@ -480,8 +496,8 @@ void LaunchCmvn(const float *raw, const UttLayout &utts, int num_utts, const flo
                 const CmvnTables *d_cmvn_tab, int left, int right, float *yt, int64_t ldy,
                 hipStream_t stream) {
   if (num_utts <= 0) return;
-  hipLaunchKernelGGL(CmvnKernel, dim3(num_utts), dim3(kWave), 0, stream, raw, utts, d_global41,
-                     d_cmvn_tab, left, right, yt, ldy);
+  hipLaunchKernelGGL(CmvnKernel, dim3(num_utts), dim3(kWave * kCmvnWaves), 0, stream, raw, utts,
+                     d_global41, d_cmvn_tab, left, right, yt, ldy);
 }
 
 void LaunchPadTranspose(const float *feats, int T, int dim, int left, int right, float *yt,

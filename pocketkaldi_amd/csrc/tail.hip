@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kTailThreads) void TailKernel(const float *__restri
 #pragma unroll
     for (int c = 0; c < kTailCache; ++c) {
       const int q = tid + c * kTailThreads;
-      if (q < n4) dst[c] = x[q];
+      if (q < n4) dst[c] = __builtin_nontemporal_load(&x[q]);
     }
   };
   int row = blockIdx.x;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kTailThreads) void TailKernel(const float *__restri
           r[e] = t;
         }
         if (vec_out) {
-          reinterpret_cast<f32x4 *>(y)[q] = r;
+          __builtin_nontemporal_store(r, &reinterpret_cast<f32x4 *>(y)[q]);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
