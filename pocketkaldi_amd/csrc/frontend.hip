@@ -15,6 +15,8 @@
 // between passes.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "pk_kernels.h"
 #include "pk_logf.h"
 
@@ -398,28 +400,34 @@ __global__ __launch_bounds__(kWave * kCmvnWaves) void CmvnKernel(
         const int t0 = i * kCmvnTile;
         const int nt = T - t0 < kCmvnTile ? T - t0 : kCmvnTile;
         // blocks of 8 frames: the LDS operands of a block are fetched first (they do not
-        // depend on the recurrence), so the serial chain is arithmetic only
+        // depend on the recurrence), so the serial chain is arithmetic only.  Whole blocks
+        // always: frames past the end of the utterance compute values nobody reads (their
+        // slots of the tile exist), and lanes 40..63 store feature 0's value on top of lane 0's.
+        // MODE 0: no frame of the tile has left the window yet; 2: all have; 1: mixed.
         constexpr int kBlk = 8;
-        for (int u0 = 0; u0 < nt; u0 += kBlk) {
-          float xs[kBlk], xo[kBlk];
+        auto walk = [&](auto mode) {
+          constexpr int MODE = decltype(mode)::value;
+          for (int u0 = 0; u0 < nt; u0 += kBlk) {
+            float xs[kBlk], xo[kBlk];
 #pragma unroll
-          for (int v = 0; v < kBlk; ++v) {
-            const int u = u0 + v < kCmvnTile ? u0 + v : kCmvnTile - 1;
-            xs[v] = xin[u * kNumBins + d];
-            xo[v] = xold[u * kNumBins + d];
-          }
+            for (int v = 0; v < kBlk; ++v) {
+              xs[v] = xin[(u0 + v) * kNumBins + d];
+              if (MODE != 0) xo[v] = xold[(u0 + v) * kNumBins + d];
+            }
 #pragma unroll
-          for (int v = 0; v < kBlk; ++v) {
-            const int u = u0 + v, t = t0 + u;
-            if (u < nt) {
+            for (int v = 0; v < kBlk; ++v) {
               double acc = s;                                 // cmvn.cc:44-52
               acc += xs[v];
-              if (t >= kCmvnWindow) acc += -1.0 * static_cast<double>(xo[v]);   // cmvn.cc:58-64
+              if (MODE == 2 || (MODE == 1 && t0 + u0 + v >= kCmvnWindow))
+                acc += -1.0 * static_cast<double>(xo[v]);     // cmvn.cc:58-64
               s = static_cast<float>(acc);                    // cmvn.cc:66-70
-              if (lane < kNumBins) sum[u * kNumBins + d] = s;
+              sum[(u0 + v) * kNumBins + d] = s;
             }
           }
-        }
+        };
+        if (t0 + kCmvnTile <= kCmvnWindow) walk(std::integral_constant<int, 0>());
+        else if (t0 >= kCmvnWindow) walk(std::integral_constant<int, 2>());
+        else walk(std::integral_constant<int, 1>());
       }
     } else if (i >= 1) {
       // writers: tile i - 1, lane = frame, features split between the two waves

@@ -39,7 +39,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 256;
-constexpr int kRing = 3;                    // LDS slabs in the ring
 
 typedef const __attribute__((address_space(1))) void *GlobalPtr;
 typedef __attribute__((address_space(3))) void *LdsPtr;
@@ -89,13 +88,23 @@ __device__ __forceinline__ void IssuePiece(const GemmArgs &a, const float *__res
   }
 }
 
-template <int S, bool SPLICE, bool MULTICHUNK, bool BIAS_J, bool RELU>
-__global__ __launch_bounds__(kThreads, 3) void GemmKernel(GemmArgs a) {
+// KG > 1 (small launches only, S = 1): the workgroup has KG groups of four waves and group g
+// takes the g-th 512-chunk of k -- the reference's own blocking (gemm.h:50) -- through its own
+// LDS ring; the groups' accumulators are then added in chunk order (gemm.cc:95-123 adds chunk
+// after chunk into C), so the result is the same bit pattern with KG times the waves in flight.
+// R = LDS slabs in a group's ring; R - 1 slabs of DMA are in flight.  R = 3 everywhere: the big
+// tiles spend 6 000 cycles on a slab with three workgroups per CU, and a deeper ring (R = 8)
+// bought the small launches nothing either (measured; they are not latency-bound).
+template <int S, bool SPLICE, bool MULTICHUNK, bool BIAS_J, bool RELU, int KG = 1, int R = 3>
+__global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void GemmKernel(GemmArgs a) {
   using G = Geo<S>;
   constexpr int kBT = G::kBT, kSlab = G::kSlab, kDma = G::kDma;
+  constexpr int kRing = R, kAhead = R - 1;
+  static_assert((kAhead - 1) * kDma <= 63, "vmcnt is a 6-bit counter");
+  static_assert(KG == 1 || (S == 1 && !SPLICE && !MULTICHUNK), "k-groups: small plain launches only");
   // ALL LDS in one array (a second __shared__ object makes hipcc drain the DMA
   // queue before every LDS read)
-  __shared__ __attribute__((aligned(16))) float smem[kRing * 2 * kSlab];
+  __shared__ __attribute__((aligned(16))) float smem_all[KG * kRing * 2 * kSlab];
 
   // ---- workgroup -> tile.  Workgroups b and b+8 share an XCD (round-robin
   // dispatch), so give each XCD a contiguous run of ids, and walk ids through
@@ -114,11 +123,14 @@ __global__ __launch_bounds__(kThreads, 3) void GemmKernel(GemmArgs a) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = KG == 1 ? 0 : wave_all >> 2;        // k-group of this wave
+  const int wave = KG == 1 ? wave_all : (wave_all & 3);
+  float *smem = smem_all + grp * (kRing * 2 * kSlab);
   const int wi = wave >> 1, wj = wave & 1;
   const int half = lane >> 5, l31 = lane & 31;
-  const float *pg = a.P + i0;
-  const float *qg = a.Q + j0;
+  const float *pg = a.P + i0 + (int64_t)grp * kChunkK * a.ldp;
+  const float *qg = a.Q + j0 + (int64_t)grp * kChunkK * a.ldq;
   // byte offset of this lane inside a DMA piece (kPieceRows k-rows, 16 bytes per lane)
   const uint32_t lane_off_p = (uint32_t)(((lane / G::kLanesPerRow) * a.ldp + (lane % G::kLanesPerRow) * 4) * sizeof(float));
   const uint32_t lane_off_q = (uint32_t)(((lane / G::kLanesPerRow) * a.ldq + (lane % G::kLanesPerRow) * 4) * sizeof(float));
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(kThreads, 3) void GemmKernel(GemmArgs a) {
       done[x][y] = f32x16{0};
     }
 
-  const int nkt = a.K / kBK;
+  const int nkt = (KG == 1 ? a.K : kChunkK) / kBK;
 
   auto issue_slab = [&](int kt, int slot) {
 #pragma unroll
@@ -171,21 +183,19 @@ __global__ __launch_bounds__(kThreads, 3) void GemmKernel(GemmArgs a) {
   };
 
   // ---- software pipeline.  Per slab kt (A = k-steps 0..3, B = k-steps 4..7):
-  //   MFMAs on A(kt) with the reads of frags B(kt) and the DMA pieces of slab kt+2 between them
+  //   MFMAs on A(kt) with the reads of frags B(kt) and the DMA pieces of slab kt+kAhead between them
   //   | wait DMA(kt+1), barrier | read frags A(kt+1) | MFMAs on B(kt)
   // Workgroups sharing a SIMD run in lockstep, so anything outside the MFMA stream is
   // idle matrix-pipe time: DMA issue and fragment reads are tucked under MFMAs, and only
   // the barrier itself is exposed.
-  // Slot reuse: DMA(kt+2) overwrites the slot of slab kt-1, whose last reads every
+  // Slot reuse: DMA(kt+kAhead) overwrites the slot of slab kt-1, whose last reads every
   // wave completed (lgkmcnt(0)) before the barrier of slab kt-1.
   float fa_p[kBK / 4][S], fa_q[kBK / 4][S], fb_p[kBK / 4][S], fb_q[kBK / 4][S];
-  issue_slab(0, 0);
-  if (nkt > 1) {
-    issue_slab(1, 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma) : "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+#pragma unroll
+  for (int s0 = 0; s0 < kAhead; ++s0)
+    if (s0 < nkt) issue_slab(s0, s0);
+  if (nkt >= kAhead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kAhead - 1) * kDma) : "memory");   // slab 0 is in
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   read_frags(0, 0, fa_p, fa_q);
@@ -193,8 +203,8 @@ __global__ __launch_bounds__(kThreads, 3) void GemmKernel(GemmArgs a) {
   int slot = 0;
   for (int kt = 0; kt < nkt; ++kt) {
     int slot1 = slot + 1 == kRing ? 0 : slot + 1;
-    int slot2 = slot1 + 1 == kRing ? 0 : slot1 + 1;
-    const bool dma = kt + 2 < nkt;
+    int slot2 = slot == 0 ? kRing - 1 : slot - 1;     // slab kt + kAhead takes the slot of slab kt - 1
+    const bool dma = kt + kAhead < nkt;
 #pragma unroll
     for (int ks = 0; ks < kBK / 4; ++ks) {
       mfma_step(fa_p, fa_q, ks);
@@ -205,17 +215,17 @@ __global__ __launch_bounds__(kThreads, 3) void GemmKernel(GemmArgs a) {
       if (dma) {
 #pragma unroll
         for (int p = ks * kDma / 4; p < (ks + 1) * kDma / 4; ++p)
-          IssuePiece<S, SPLICE>(a, pg, qg, (kt + 2) * kBK, wave, lane, lane_off_p, lane_off_q, smem, slot2, p);
+          IssuePiece<S, SPLICE>(a, pg, qg, (kt + kAhead) * kBK, wave, lane, lane_off_p, lane_off_q, smem, slot2, p);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     // slab kt+1 must have landed (this wave's DMAs; the barrier covers the others');
-    // slab kt+2 stays in flight across the barrier.  Raw s_barrier: __syncthreads()
+    // the later slabs stay in flight across the barrier.  Raw s_barrier: __syncthreads()
     // would drain the DMA queue.
     // (the LDS wait is the builtin form so that hipcc's own wait bookkeeping sees it:
     // after an asm wait it re-waits lgkmcnt(0) behind the next reads)
     __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0) only
-    if (dma) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma) : "memory");
+    if (dma) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kAhead - 1) * kDma) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -238,6 +248,23 @@ __global__ __launch_bounds__(kThreads, 3) void GemmKernel(GemmArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);
     slot = slot1;
+  }
+
+  if (KG > 1) {
+    // every wave is past its last barrier, so no slab is read any more: the rings become the
+    // exchange area, [group - 1][wave][register][lane]
+    float *xch = smem_all;
+    if (grp > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xch[(((grp - 1) * 4 + wave) * 16 + r) * 64 + lane] = acc[0][0][r];
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g = 1; g < KG; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][0][r] = acc[0][0][r] + xch[(((g - 1) * 4 + wave) * 16 + r) * 64 + lane];
   }
 
   // ---- epilogue.  Accumulator acc[x][y], register r, lane (l31, half) holds
@@ -279,14 +306,14 @@ __global__ __launch_bounds__(kThreads, 3) void GemmKernel(GemmArgs a) {
   }
 }
 
-template <int S, bool SPLICE, bool MULTICHUNK>
+template <int S, bool SPLICE, bool MULTICHUNK, int KG = 1, int R = 3>
 void LaunchVariant(const GemmArgs &a, dim3 grid, dim3 block, hipStream_t stream) {
   if (a.bias_on_j) {
-    if (a.relu) hipLaunchKernelGGL((GemmKernel<S, SPLICE, MULTICHUNK, true, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((GemmKernel<S, SPLICE, MULTICHUNK, true, false>), grid, block, 0, stream, a);
+    if (a.relu) hipLaunchKernelGGL((GemmKernel<S, SPLICE, MULTICHUNK, true, true, KG, R>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((GemmKernel<S, SPLICE, MULTICHUNK, true, false, KG, R>), grid, block, 0, stream, a);
   } else {
-    if (a.relu) hipLaunchKernelGGL((GemmKernel<S, SPLICE, MULTICHUNK, false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((GemmKernel<S, SPLICE, MULTICHUNK, false, false>), grid, block, 0, stream, a);
+    if (a.relu) hipLaunchKernelGGL((GemmKernel<S, SPLICE, MULTICHUNK, false, true, KG, R>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((GemmKernel<S, SPLICE, MULTICHUNK, false, false, KG, R>), grid, block, 0, stream, a);
   }
 }
 
@@ -297,12 +324,20 @@ void LaunchGeo(const GemmArgs &a, hipStream_t stream) {
   const int nblk = super_i * super_j * 64;
   const bool multi = a.K > kChunkK;
   dim3 grid(nblk), block(kThreads);
+  // a launch that leaves most SIMDs with one wave: one k-group per 512-chunk (KG x the waves)
+  if (S == 1 && a.splice_dim == 0 && nblk <= 768 && a.K % kChunkK == 0) {
+    const int kg = a.K / kChunkK;
+    if (kg == 2) return LaunchVariant<1, false, false, 2>(a, grid, dim3(kThreads * 2), stream);
+    if (kg == 3) return LaunchVariant<1, false, false, 3>(a, grid, dim3(kThreads * 3), stream);
+    if (kg == 4) return LaunchVariant<1, false, false, 4>(a, grid, dim3(kThreads * 4), stream);
+  }
+  constexpr int kR = 3;
   if (a.splice_dim > 0) {
-    if (multi) LaunchVariant<S, true, true>(a, grid, block, stream);
-    else LaunchVariant<S, true, false>(a, grid, block, stream);
+    if (multi) LaunchVariant<S, true, true, 1, kR>(a, grid, block, stream);
+    else LaunchVariant<S, true, false, 1, kR>(a, grid, block, stream);
   } else {
-    if (multi) LaunchVariant<S, false, true>(a, grid, block, stream);
-    else LaunchVariant<S, false, false>(a, grid, block, stream);
+    if (multi) LaunchVariant<S, false, true, 1, kR>(a, grid, block, stream);
+    else LaunchVariant<S, false, false, 1, kR>(a, grid, block, stream);
   }
 }
 

@@ -155,7 +155,10 @@ def test_affine_bit_exact_vs_committed_reference_gemm():
 
 
 @pytest.mark.parametrize("shape", [(1, 3, 4), (7, 440, 1024), (129, 1024, 1024), (300, 2048, 130),
-                                   (5, 513, 3000), (257, 17, 9)])
+                                   (5, 513, 3000), (257, 17, 9),
+                                   # K = 2, 3, 4 chunks of 512 on a small launch: one k-group of waves
+                                   # per chunk, added in chunk order (gemm.cc:95-123)
+                                   (998, 1024, 1024), (200, 1536, 256), (64, 2048, 2048), (70, 2560, 64)])
 def test_affine_relu_bit_exact_vs_oracle(shape):
     T, K, N = shape
     rng = np.random.default_rng(T * 7 + K)
