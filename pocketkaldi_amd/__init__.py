@@ -71,7 +71,8 @@ EXPORTS = [
 
 
 def lib_path():
-    return os.path.join(_HERE, "libpk_mi355.so")
+    # PK_MI355_LIB: developer override (A/B builds of the kernels); the product is the in-tree library
+    return os.environ.get("PK_MI355_LIB") or os.path.join(_HERE, "libpk_mi355.so")
 
 
 def lib():
