@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--model", default="S", choices=["S", "W", "tiny"])
     ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
                     help="f32: bit-exact fp32 MFMA (default); f16x3: split-fp16 on the fp16 matrix cores")
+    ap.add_argument("--softmax", default="stable", choices=["stable", "reference"],
+                    help="stable: overflow-safe log-softmax tail (default); reference: the reference's softmax "
+                         "operations one by one -- with f32 the whole path is then bit-identical to the CPU path")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo = rehearsal of the multi-rank flow, e.g. two ranks on ONE GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -195,7 +198,7 @@ def main():
         layers = [(l[0], np.zeros_like(l[1]), np.zeros_like(l[2])) if l[0] == "linear" else l
                   for l in layers]
         prior = np.full_like(prior, 1.0)
-    am = pk.AcousticModel(layers, prior, L, R, precision=args.precision)
+    am = pk.AcousticModel(layers, prior, L, R, precision=args.precision).set_softmax(args.softmax)
     import torch.distributed as tdist
     if world > 1 or tdist.is_initialized():
         ptr, nbytes = am.blob()
@@ -247,7 +250,7 @@ def main():
     if not args.no_other_precision:
         other_prec = "f16x3" if args.precision == "f32" else "f32"
         bs.close()
-        am2 = pk.AcousticModel(layers, prior, L, R, precision=other_prec)
+        am2 = pk.AcousticModel(layers, prior, L, R, precision=other_prec).set_softmax(args.softmax)
         if world > 1 or tdist.is_initialized():
             ptr2, nbytes2 = am2.blob()
             pkdist.broadcast_blob(pkdist.alias_device_bytes(ptr2, nbytes2, dev), src=0)
@@ -281,7 +284,7 @@ def main():
             "config": {"workload": "%d utterances x %.0f s 16 kHz per GPU (BASELINE configs[2]; x8 = configs[3]), "
                                    "440 -> %d x %d ReLU -> %d softmax, fbank+CMVN+nnet, PCM resident in HBM"
                                    % (args.batch, args.seconds, nh, hidden, pdfs),
-                       "model": args.model, "utterances_per_gpu": args.batch,
+                       "model": args.model, "softmax": args.softmax, "utterances_per_gpu": args.batch,
                        "frames_per_gpu_per_step": int(frames_per_step),
                        "parallelism": "utterance-sharded x%d, weights broadcast once (%s)" % (
                            world, "RCCL" if args.backend == "nccl" else "gloo rehearsal")},

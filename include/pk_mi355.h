@@ -115,6 +115,17 @@ enum { PK_MI355_PRECISION_F32 = 0, PK_MI355_PRECISION_F16X3 = 1 };
 int pk_mi355_am_set_precision(pk_mi355_am_t *am, int precision);
 int pk_mi355_am_precision(const pk_mi355_am_t *am);
 
+/* Arithmetic of the softmax / log-likelihood tail (any time; default STABLE).
+ *   STABLE    : log-softmax with the row maximum subtracted -- finite for any logits, within
+ *               1e-6 of the reference wherever the reference does not overflow.
+ *   REFERENCE : the reference's operations one by one (nnet.cc:38-47 -> vector.cc:265-277,
+ *               am.cc:106-112): libm expf, float sum in column order, division, floor,
+ *               libm logf, prior, scale.  With F32 precision the log-likelihoods are then the
+ *               reference's bit patterns, its overflow for logits above 88.7 included.       */
+enum { PK_MI355_SOFTMAX_STABLE = 0, PK_MI355_SOFTMAX_REFERENCE = 1 };
+int pk_mi355_am_set_softmax(pk_mi355_am_t *am, int mode);
+int pk_mi355_am_softmax(const pk_mi355_am_t *am);
+
 /* AcousticModel::Read tail, am.cc:41-60: prior holds probabilities (the log is
  * taken here); tid2pdf is indexed by transition-id.  tid2pdf may be NULL (then
  * pk_decodable_loglikelihood treats trans_id as the pdf index).  Uploads the

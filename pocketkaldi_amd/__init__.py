@@ -54,7 +54,7 @@ EXPORTS = [
     "pk_mi355_last_error", "pk_mi355_set_device", "pk_decodable_init", "pk_decodable_destroy",
     "pk_decodable_loglikelihood", "pk_decodable_islastframe", "pk_mi355_am_create",
     "pk_mi355_am_destroy", "pk_mi355_am_add_linear", "pk_mi355_am_add_layer",
-    "pk_mi355_am_finalize", "pk_mi355_am_set_precision", "pk_mi355_am_precision", "pk_mi355_am_read", "pk_mi355_load", "pk_mi355_am_num_pdfs", "pk_mi355_am_input_dim",
+    "pk_mi355_am_finalize", "pk_mi355_am_set_precision", "pk_mi355_am_precision", "pk_mi355_am_set_softmax", "pk_mi355_am_softmax", "pk_mi355_am_read", "pk_mi355_load", "pk_mi355_am_num_pdfs", "pk_mi355_am_input_dim",
     "pk_mi355_am_transition_to_pdf", "pk_mi355_am_blob_device_ptr", "pk_mi355_am_blob_bytes",
     "pk_mi355_nnet_propagate", "pk_mi355_num_frames", "pk_mi355_fbank_compute",
     "pk_mi355_cmvn_apply", "pk_mi355_batch_create", "pk_mi355_batch_destroy",
@@ -110,6 +110,8 @@ def lib():
     L.pk_mi355_am_finalize.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, i32p, C.c_int]
     L.pk_mi355_am_read.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int,
                                    C.c_int]
+    L.pk_mi355_am_set_softmax.argtypes = [C.c_void_p, C.c_int]
+    L.pk_mi355_am_softmax.argtypes = [C.c_void_p]
     L.pk_mi355_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p), f32p]
     L.pk_mi355_am_num_pdfs.argtypes = [C.c_void_p]
     L.pk_mi355_am_input_dim.argtypes = [C.c_void_p]
@@ -308,6 +310,11 @@ class AcousticModel:
         _check(lib().pk_mi355_load(config_path.encode(), cls.PRECISIONS[precision], C.byref(h), _fp(stats)))
         self._h = h.value
         return self, stats
+
+    def set_softmax(self, mode):
+        """"stable" (default): overflow-safe log-softmax; "reference": the reference's operations one by one."""
+        _check(lib().pk_mi355_am_set_softmax(self._h, {"stable": 0, "reference": 1}[mode]))
+        return self
 
     def close(self):
         if getattr(self, "_h", None):

@@ -165,6 +165,7 @@ struct pk_mi355_am {
   std::vector<HostLayer> layers;
   bool finalized = false;
   int precision = PK_MI355_PRECISION_F32;
+  bool softmax_reference = false;  // PK_MI355_SOFTMAX_REFERENCE: the reference's softmax operations one by one
   int left = 0, right = 0, num_pdfs = 0;
   int input_dim = 0, output_dim = 0, feat_dim = 0;
   int max_dim_pad = 0;             // widest activation, rounded to the tile
@@ -342,13 +343,13 @@ int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t
         const bool final_layer = (i == nl - 1);
         Scoped t(timer, PK_MI355_K_TAIL, stream);
         if (final_layer && want_tail) {
-          LaunchTail(kTailSoftmaxLoglik, cur, cur_ld, rows, cur_dim, blob + am->logprior_off, scale,
-                     tail_out, tail_ld, stream);
+          LaunchTail(kTailSoftmaxLoglik, am->softmax_reference, cur, cur_ld, rows, cur_dim,
+                     blob + am->logprior_off, scale, tail_out, tail_ld, stream);
           tail_done = true;
         } else {
           float *dst = bufs[next_buf];
           const int64_t ld = RoundUp(cur_dim, kTile);
-          LaunchTail(kTailSoftmaxProb, cur, cur_ld, rows_pad, cur_dim, nullptr, 1.0f, dst, ld, stream);
+          LaunchTail(kTailSoftmaxProb, am->softmax_reference, cur, cur_ld, rows_pad, cur_dim, nullptr, 1.0f, dst, ld, stream);
           cur = dst; cur_ld = ld; next_buf ^= 1;
         }
         break;
@@ -364,8 +365,8 @@ int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t
   if (want_tail && !tail_done) {
     if (cur_dim > 8192) return Fail(PK_MI355_E_INVALID, "output wider than 8192 is not supported");
     Scoped t(timer, PK_MI355_K_TAIL, stream);
-    LaunchTail(kTailLoglik, cur, cur_ld, rows, cur_dim, blob + am->logprior_off, scale, tail_out,
-               tail_ld, stream);
+    LaunchTail(kTailLoglik, am->softmax_reference, cur, cur_ld, rows, cur_dim, blob + am->logprior_off,
+               scale, tail_out, tail_ld, stream);
   }
   if (res) { res->data = cur; res->ld = cur_ld; res->dim = cur_dim; }
   hipError_t le = hipGetLastError();
@@ -417,11 +418,11 @@ int RunLayersF16(const pk_mi355_am *am, const ExecBufs &e, const _Float16 *x, in
   const float *cur = e.a;
   if (want_tail) {
     Scoped t(timer, PK_MI355_K_TAIL, stream);
-    LaunchTail(softmax_last ? kTailSoftmaxLoglik : kTailLoglik, cur, out_ld, rows, dim,
+    LaunchTail(softmax_last ? kTailSoftmaxLoglik : kTailLoglik, am->softmax_reference, cur, out_ld, rows, dim,
                blob + am->logprior_off, scale, tail_out, tail_ld, stream);
   } else if (softmax_last) {
     Scoped t(timer, PK_MI355_K_TAIL, stream);
-    LaunchTail(kTailSoftmaxProb, cur, out_ld, rows_pad, dim, nullptr, 1.0f, e.b, out_ld, stream);
+    LaunchTail(kTailSoftmaxProb, am->softmax_reference, cur, out_ld, rows_pad, dim, nullptr, 1.0f, e.b, out_ld, stream);
     cur = e.b;
   }
   if (res) { res->data = cur; res->ld = out_ld; res->dim = dim; }
@@ -615,6 +616,18 @@ int pk_mi355_am_set_precision(pk_mi355_am_t *am, int precision) {
 }
 
 int pk_mi355_am_precision(const pk_mi355_am_t *am) { return am ? am->precision : 0; }
+
+int pk_mi355_am_set_softmax(pk_mi355_am_t *am, int mode) {
+  if (!am) return Fail(PK_MI355_E_INVALID, "null model");
+  if (mode != PK_MI355_SOFTMAX_STABLE && mode != PK_MI355_SOFTMAX_REFERENCE)
+    return Fail(PK_MI355_E_INVALID, "unknown softmax mode %d", mode);
+  am->softmax_reference = mode == PK_MI355_SOFTMAX_REFERENCE;
+  return 0;
+}
+
+int pk_mi355_am_softmax(const pk_mi355_am_t *am) {
+  return am && am->softmax_reference ? PK_MI355_SOFTMAX_REFERENCE : PK_MI355_SOFTMAX_STABLE;
+}
 
 int pk_mi355_am_finalize(pk_mi355_am_t *am, const float *prior, int num_pdfs, int left_context,
                          int right_context, const int32_t *tid2pdf, int num_tids) {

@@ -122,9 +122,11 @@ enum TailMode {
                            //   (max(log p, log 1e-20) - log_prior) * scale
   kTailLoglik = 2          // no softmax layer: (log(max(x, 1e-20)) - log_prior) * scale
 };
-// in: [rows][ld_in] frame-major; out: [rows][ld_out]; n valid columns.
-void LaunchTail(int mode, const float *in, int64_t ld_in, int rows, int n, const float *log_prior,
-                float scale, float *out, int64_t ld_out, hipStream_t stream);
+// in: [rows][ld_in] frame-major; out: [rows][ld_out]; n valid columns.  reference_exact: the
+// softmax modes reproduce the reference's operations one by one (libm expf, in-order float
+// sum, division, libm logf) instead of the overflow-safe log-softmax.
+void LaunchTail(int mode, bool reference_exact, const float *in, int64_t ld_in, int rows, int n,
+                const float *log_prior, float scale, float *out, int64_t ld_out, hipStream_t stream);
 
 // Device-side pk_decodable_loglikelihood (decodable.cc:24-31) for n (frame, trans_id) pairs.
 void LaunchGather(const float *ll, int64_t ld, const int32_t *tid2pdf, int num_tids,

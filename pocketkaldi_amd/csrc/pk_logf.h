@@ -8,7 +8,8 @@
 // log(x) = log1p(z/c - 1) + log(c) + k ln2 with a cubic in double -- so that the GPU features
 // are the reference's bit for bit.  tools/logf_check.c compares it with the system logf over
 // every positive finite float (2 139 095 039 values, no mismatch, with and without fused
-// multiply-adds); tests/cpp/logf_test.cc repeats a strided sweep in the CPU suite.
+// multiply-adds); tests/cpp/libm_restated_test.cc repeats a strided
+// sweep in the CPU suite.
 #ifndef PK_LOGF_H_
 #define PK_LOGF_H_
 

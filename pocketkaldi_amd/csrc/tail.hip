@@ -5,7 +5,9 @@
 // changes between feature-major panels and frame-major rows.  All HBM-bound.
 #include <hip/hip_runtime.h>
 
+#include "pk_expf.h"
 #include "pk_kernels.h"
+#include "pk_logf.h"
 
 #pragma clang fp contract(off)
 
@@ -14,6 +16,10 @@ namespace pkmi {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// the C library's logf / expf tables (pk_logf.h, pk_expf.h)
+__device__ const double kLogfTab[kLogfTableDoubles] = PK_LOGF_TABLE_INIT;
+__device__ const uint64_t kExpfTab[kExpfTableWords] = PK_EXPF_TABLE_INIT;
 
 __global__ void ReluKernel(float *__restrict__ x, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(kTailThreads) void TailKernel(const float *__restri
             t = expf(t - m) * inv;
           } else {
             if (MODE == kTailSoftmaxLoglik) t = t - lse;          // log softmax, stable form
-            else t = logf(t < 1.0e-20f ? 1.0e-20f : t);           // am.cc:109-110
+            else t = LogfRestated(t < 1.0e-20f ? 1.0e-20f : t, kLogfTab);   // am.cc:109-110, libm's logf
             if (t < kLogFloor) t = kLogFloor;                      // floor of am.cc:109 in the log domain
             t = (t + -1.0f * lp[c][e]) * scale;                    // am.cc:111, decodable.cc:15
           }
@@ -239,6 +245,105 @@ void LaunchTransposeToCols(const float *in, int64_t ld_in, int frames, int dim, 
                      ld_out);
 }
 
+// ---- the softmax tail exactly as the reference computes it (opt-in, PK_MI355_SOFTMAX_REFERENCE).
+// vector.cc:265-277: e_j = expf(x_j); sum = e_0 + e_1 + ... accumulated in float, in order;
+// p_j = e_j / sum.  am.cc:106-112: logf(max(p, 1e-20)) - log_prior; decodable.cc:15: x scale.
+// With the C library's expf / logf restated (pk_expf.h, pk_logf.h) every operation is the
+// reference's, so the log-likelihoods are its bit patterns (overflow for logits > 88.7 and all).
+//
+// The sum is a 3 000-term serial chain per frame, so frames go on lanes: a workgroup owns 64
+// frames; four producer waves stream 64 x 64 tiles of logits (coalesced 256-byte row pieces),
+// exponentiate them and leave e in LDS, and a fifth wave -- lane = frame -- adds tile after
+// tile in column order, one tile behind the producers.  A second pass re-reads the logits
+// (the 64 x n block cannot stay on chip) and finishes every element in parallel.
+
+constexpr int kXRows = 64, kXCols = 64, kXLd = kXCols + 1;
+constexpr int kXProducers = 4;                         // waves; each owns 16 rows of a tile
+
+template <int MODE>
+__global__ __launch_bounds__(64 * (kXProducers + 1)) void TailExactKernel(
+    const float *__restrict__ in, int64_t ld_in, int rows, int n, const float *__restrict__ log_prior,
+    float scale, float *__restrict__ out, int64_t ld_out) {
+  __shared__ float tile[2][kXRows * kXLd];
+  __shared__ float s_sum[kXRows];
+  __shared__ double s_logf[kLogfTableDoubles];
+  __shared__ uint64_t s_expf[kExpfTableWords];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // 0..3 producers, 4 the chain
+  if (threadIdx.x < kLogfTableDoubles) s_logf[threadIdx.x] = kLogfTab[threadIdx.x];
+  if (threadIdx.x < kExpfTableWords) s_expf[threadIdx.x] = kExpfTab[threadIdx.x];
+  const int r0 = blockIdx.x * kXRows;
+  const int ntiles = (n + kXCols - 1) / kXCols;
+  constexpr int kPer = kXRows / kXProducers;            // rows of a tile per producer wave
+  // this thread's rows (clamped: a partial block recomputes its last row, stores are masked)
+  const float *xrow[kPer];
+  if (wv < kXProducers) {
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      int r = r0 + wv * kPer + i;
+      if (r > rows - 1) r = rows - 1;
+      xrow[i] = in + (int64_t)r * ld_in;
+    }
+  }
+  __syncthreads();
+
+  // ---- pass 1: sum_j expf(x_j) in column order
+  float s = 0.0f;
+  float xv[kPer];
+  auto load_tile = [&](int t) {
+    const int c = t * kXCols + lane;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) xv[i] = c < n ? __builtin_nontemporal_load(xrow[i] + c) : 0.0f;
+  };
+  if (wv < kXProducers) load_tile(0);
+  for (int t = 0; t <= ntiles; ++t) {
+    if (wv < kXProducers) {
+      if (t < ntiles) {
+        float ev[kPer];
+        const bool live = t * kXCols + lane < n;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) ev[i] = live ? ExpfRestated(xv[i], s_expf) : 0.0f;   // + 0 leaves a sum as it is
+        if (t + 1 < ntiles) load_tile(t + 1);       // (requesting these before the arithmetic measured slower)
+        float *dst = tile[t & 1] + (wv * kPer) * kXLd + lane;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) dst[i * kXLd] = ev[i];
+      }
+    } else if (t >= 1) {
+      const float *src = tile[(t - 1) & 1] + lane * kXLd;
+#pragma unroll 16
+      for (int c = 0; c < kXCols; ++c) s += src[c];                    // vector.cc:271
+    }
+    __syncthreads();
+  }
+  if (wv == kXProducers) s_sum[lane] = s;
+  __syncthreads();
+  if (wv == kXProducers) return;
+
+  // ---- pass 2: p = e / sum (vector.cc:274-276) and the log-likelihood arithmetic
+  float sum_r[kPer];
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) sum_r[i] = s_sum[wv * kPer + i];
+  for (int t = 0; t < ntiles; ++t) {
+    const int c = t * kXCols + lane;
+    if (c >= n) break;
+    const float lp = MODE == kTailSoftmaxLoglik ? log_prior[c] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) xv[i] = xrow[i][c];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      float p = ExpfRestated(xv[i], s_expf);
+      p /= sum_r[i];
+      if (MODE == kTailSoftmaxLoglik) {
+        if (p < 1.0e-20f) p = 1.0e-20f;                               // am.cc:109
+        p = LogfRestated(p, s_logf);                                   // am.cc:110
+        p = (p + -1.0f * lp) * scale;                                  // am.cc:111, decodable.cc:15
+      }
+      const int r = r0 + wv * kPer + i;
+      if (r < rows) __builtin_nontemporal_store(p, out + (int64_t)r * ld_out + c);
+    }
+  }
+}
+
 template <int MODE>
 static void LaunchTailMode(const float *in, int64_t ld_in, int rows, int n, const float *log_prior,
                            float scale, float *out, int64_t ld_out, hipStream_t stream) {
@@ -252,9 +357,17 @@ static void LaunchTailMode(const float *in, int64_t ld_in, int rows, int n, cons
     hipLaunchKernelGGL((TailKernel<MODE, kTailCacheMax>), grid, block, 0, stream, in, ld_in, rows, n, log_prior, scale, out, ld_out);
 }
 
-void LaunchTail(int mode, const float *in, int64_t ld_in, int rows, int n, const float *log_prior,
-                float scale, float *out, int64_t ld_out, hipStream_t stream) {
+void LaunchTail(int mode, bool reference_exact, const float *in, int64_t ld_in, int rows, int n,
+                const float *log_prior, float scale, float *out, int64_t ld_out, hipStream_t stream) {
   if (rows <= 0 || n <= 0) return;
+  if (reference_exact && mode != kTailLoglik) {
+    dim3 grid((rows + kXRows - 1) / kXRows), block(64 * (kXProducers + 1));
+    if (mode == kTailSoftmaxProb)
+      hipLaunchKernelGGL((TailExactKernel<kTailSoftmaxProb>), grid, block, 0, stream, in, ld_in, rows, n, log_prior, scale, out, ld_out);
+    else
+      hipLaunchKernelGGL((TailExactKernel<kTailSoftmaxLoglik>), grid, block, 0, stream, in, ld_in, rows, n, log_prior, scale, out, ld_out);
+    return;
+  }
   switch (mode) {
     case kTailSoftmaxProb:
       LaunchTailMode<kTailSoftmaxProb>(in, ld_in, rows, n, log_prior, scale, out, ld_out, stream);

@@ -31,11 +31,12 @@ def test_cpp_caller_runs_reference_style_tests():
     assert "hot_path_test ok" in out
 
 
-def test_device_logf_restatement_matches_libm_on_cpu():
-    """csrc/pk_logf.h, the logf of the front-end kernel, compiled for the host and compared with
-    the C library's logf on ~35 M floats (tests/cpp/logf_test.cc; exhaustive: tools/logf_check.c)."""
-    src = os.path.join(REPO, "tests", "cpp", "logf_test.cc")
-    binary = os.path.join(REPO, "tests", "cpp", "logf_test.bin")
+def test_device_logf_expf_restatements_match_libm_on_cpu():
+    """csrc/pk_logf.h / pk_expf.h, the logf and expf of the kernels, compiled for the host and compared
+    with the C library's on ~70 M floats (tests/cpp/libm_restated_test.cc; exhaustive sweeps:
+    tools/logf_check.c, tools/expf_check.c)."""
+    src = os.path.join(REPO, "tests", "cpp", "libm_restated_test.cc")
+    binary = os.path.join(REPO, "tests", "cpp", "libm_restated_test.bin")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", src, "-o", binary, "-lm"])
     out = subprocess.check_output([binary], text=True)
     assert out.strip().endswith(" 0 mismatches"), out

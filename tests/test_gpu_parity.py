@@ -600,3 +600,68 @@ def test_fetch_all_views_match_per_utterance_fetch():
         d = bs.fetch(u)
         assert np.array_equal(v.log_prob().view(np.uint32), d.log_prob().view(np.uint32))
         d.destroy()
+
+
+# ------------------------------------------------------------------ reference softmax mode
+# PK_MI355_SOFTMAX_REFERENCE: the reference's softmax / log operations one by one (libm expf and
+# logf restated, csrc/pk_expf.h / pk_logf.h; float sum in column order; IEEE division).  With F32
+# layers the whole path is then the reference's bit patterns.
+
+def _bits_equal_nan(a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    both_nan = np.isnan(a) & np.isnan(b)
+    return a.shape == b.shape and np.array_equal(np.where(both_nan, 0, a.view(np.uint32)),
+                                                 np.where(both_nan, 0, b.view(np.uint32)))
+
+
+@pytest.mark.parametrize("T,N", [(1, 50), (63, 64), (64, 65), (129, 3000), (70, 8000)])
+def test_reference_softmax_probabilities_bit_exact(T, N):
+    rng = np.random.default_rng(T + N)
+    W = (rng.standard_normal((N, 48)) * 0.4).astype(np.float32)
+    layers = [("linear", W, (rng.standard_normal(N) * 0.5).astype(np.float32)), ("softmax",)]
+    x = rng.standard_normal((T, 48)).astype(np.float32)
+    am = pk.AcousticModel(layers, num_pdfs=N).set_softmax("reference")
+    assert bits_equal(am.propagate(x), O.Nnet(layers).propagate(x))
+
+
+@pytest.mark.parametrize("T", [1, 47, 300])
+def test_reference_softmax_decodable_bit_exact(T):
+    layers, prior, L, R, tid2pdf = tiny_model()
+    feats = np.random.default_rng(T).standard_normal((T, 40)).astype(np.float32)
+    am = pk.AcousticModel(layers, prior, L, R, tid2pdf).set_softmax("reference")
+    assert bits_equal(pk.Decodable(am, 0.1, feats).log_prob(), O.Nnet(layers).am_compute(feats, prior, L, R, 0.1))
+
+
+def test_reference_softmax_overflow_like_the_reference():
+    """Logits above 88.7: expf overflows, the sum is inf, that element becomes inf/inf = NaN and the
+    rest of the row e/inf = 0 -> floor (vector.cc:265-277 has no max subtraction).  Same here."""
+    N = 200
+    W = np.zeros((N, 40), np.float32)
+    b = np.linspace(-120.0, 95.0, N).astype(np.float32)        # some logits beyond 88.72, some below -103.97
+    layers = [("linear", W, b), ("softmax",)]
+    prior = np.full(N, 1.0 / N, np.float32)
+    feats = np.zeros((5, 40), np.float32)
+    ref = O.Nnet(layers).am_compute(feats, prior, 0, 0, 0.1)
+    am = pk.AcousticModel(layers, prior, 0, 0).set_softmax("reference")
+    gpu = pk.Decodable(am, 0.1, feats).log_prob()
+    assert np.isnan(ref).any() and _bits_equal_nan(gpu, ref)
+    # the default tail stays finite on the same input
+    am2 = pk.AcousticModel(layers, prior, 0, 0)
+    assert np.isfinite(pk.Decodable(am2, 0.1, feats).log_prob()).all()
+
+
+def test_reference_softmax_whole_path_is_bit_identical_to_the_reference():
+    """PCM -> fbank -> CMVN -> splice -> 4 x 1024 ReLU -> 3000 softmax -> log-likelihoods, model S,
+    three ragged utterances in one batch: every float equals the CPU path's."""
+    layers, prior, L, R = synth.model("S")
+    g = synth.global_cmvn_stats()
+    waves = [synth.utterance(70 + u, seconds=s) for u, s in enumerate([2.0, 0.7, 7.1])]   # 7.1 s: the window slides
+    am = pk.AcousticModel(layers, prior, L, R).set_softmax("reference")
+    bs = pk.BatchScorer(am, g, len(waves), sum(len(w) for w in waves))
+    bs.set_waves(waves)
+    bs.score(0.1)
+    nn = O.Nnet(layers)
+    for u, w in enumerate(waves):
+        ref = nn.am_compute(O.cmvn(g, O.Fbank().compute(w)), prior, L, R, 0.1)
+        assert bits_equal(bs.fetch(u).log_prob(), ref)
