@@ -267,6 +267,20 @@ def main():
                            "fp16 matrix cores, log-likelihoods within 1e-4*max(|ref|,1) (measured ~1e-6), tests/test_gpu_parity.py"}
         bs2.close()
 
+    # ---- supplementary: the same workload with the reference's softmax arithmetic (bit-identical path)
+    ref_softmax = None
+    if not args.no_other_precision and args.softmax == "stable" and args.precision == "f32":
+        am.set_softmax("reference")
+        bs3 = pk.BatchScorer(am, synth.global_cmvn_stats(), args.batch, int(sum(ns)))
+        bs3.set_waves_device(pcm.data_ptr(), ns, keep_alive=pcm)
+        dt3, tm3 = timed_steps(bs3)
+        ref_softmax = {"softmax": "reference", "value": total_frames * args.steps / dt3, "unit": "frames/s",
+                       "ms_per_step": dt3 / args.steps * 1e3, "stage_ms_per_step": {k: tm3[k][0] for k in pk.KINDS},
+                       "parity": "every stage bit-identical to the reference CPU path (tests/test_gpu_parity.py::"
+                                 "test_reference_softmax_whole_path_is_bit_identical_to_the_reference)"}
+        bs3.close()
+        am.set_softmax("stable")
+
     if rank == 0:
         value = total_frames * args.steps / dt
         gemm_ms, gemm_launches = tm["gemm"]
@@ -300,6 +314,8 @@ def main():
         }
         if other is not None:
             out["other_precision"] = other
+        if ref_softmax is not None:
+            out["reference_softmax"] = ref_softmax
         # the HBM-bound stages against the 8 TB/s peak (algorithmic
         # bytes per frame = 800 fbank, 320 CMVN, 2 * 4 * num_pdfs log-softmax tail)
         hbm_peak = 8000.0
