@@ -105,6 +105,63 @@ static void TestLinearLayerThroughDecodable() {              // test/nnet_test.c
   CHECK(d.log_prob.data == nullptr);
 }
 
+// The throughput recipe of INTEGRATION.md section 2: two batches alternating, int16 PCM in
+// page-locked memory, results fetched as views of the batch's page-locked arena.
+static void TestPipelinedBatches(const std::string &dir) {
+  std::vector<float> wav = ReadWav16(dir + "en-us-hello.wav");
+  std::vector<float> stats = ReadVec0(dir + "cmvn_stats.bin");
+  CHECK(wav.size() == 7802 && stats.size() == 41);
+  // 40 -> 8 softmax scorer, no context
+  std::vector<float> W(8 * 40), b(8, 0.0f), prior(8, 0.125f);
+  for (size_t i = 0; i < W.size(); ++i) W[i] = 0.01f * (float)((int)(i * 7919 % 31) - 15);
+  AcousticModel am;
+  CHECK(am.AddLinear(40, 8, W.data(), b.data()).ok());
+  CHECK(am.AddLayer(PK_NNET_SOFTMAX_LAYER).ok());
+  CHECK(am.Finalize(prior, 0, 0, {}).ok());
+
+  const int kUtts = 3;
+  const int ns[kUtts] = {7802, 4000, 399};             // the last one is shorter than a frame
+  int16_t *pcm = static_cast<int16_t *>(pk_mi355_host_malloc(sizeof(int16_t) * (7802 + 4000 + 399)));
+  CHECK(pcm != nullptr);
+  int64_t off = 0;
+  for (int u = 0; u < kUtts; ++u)
+    for (int i = 0; i < ns[u]; ++i) pcm[off++] = (int16_t)wav[i];
+
+  pk_mi355_batch_t *batch[2];
+  for (int k = 0; k < 2; ++k) {
+    batch[k] = pk_mi355_batch_create(am.handle(), stats.data(), kUtts, off);
+    CHECK(batch[k] != nullptr);
+  }
+  pk_decodable_t views[2][kUtts];
+  for (int round = 0; round < 3; ++round) {
+    for (int k = 0; k < 2; ++k) {                      // queue both: k = 1 scores while k = 0 copies
+      CHECK(pk_mi355_batch_set_waves_i16(batch[k], pcm, ns, kUtts) == 0);
+      CHECK(pk_mi355_batch_score(batch[k], 0.1f, /*sync=*/0) == 0);
+      CHECK(pk_mi355_batch_fetch_all(batch[k], views[k], kUtts, /*sync=*/0) == 0);
+    }
+    for (int k = 0; k < 2; ++k) {
+      CHECK(pk_mi355_batch_synchronize(batch[k]) == 0);
+      for (int u = 0; u < kUtts; ++u) {
+        pk_decodable_t owned;                          // the malloc'd copy of the same utterance
+        CHECK(pk_mi355_batch_fetch(batch[k], u, &owned) == 0);
+        const int T = pk_mi355_batch_num_frames(batch[k], u);
+        CHECK(views[k][u].log_prob.ncol == T && owned.log_prob.ncol == T);
+        if (T > 0) {
+          CHECK(views[k][u].log_prob.nrow == 8);
+          CHECK(memcmp(views[k][u].log_prob.data, owned.log_prob.data, sizeof(float) * 8 * T) == 0);
+          CHECK(pk_decodable_islastframe(&views[k][u], T - 1));
+          CHECK(pk_decodable_loglikelihood(&views[k][u], 0, 3) == views[k][u].log_prob.data[3]);
+        }
+        pk_decodable_destroy(&owned);
+        pk_decodable_destroy(&views[k][u]);            // a view: frees nothing
+      }
+    }
+  }
+  CHECK(pk_mi355_batch_num_frames(batch[0], 0) == 47 && pk_mi355_batch_num_frames(batch[0], 2) == 0);
+  for (int k = 0; k < 2; ++k) pk_mi355_batch_destroy(batch[k]);
+  pk_mi355_host_free(pcm);
+}
+
 int main(int argc, char **argv) {
   if (argc > 1 && strcmp(argv[1], "--link-only") == 0) {
     printf("%s\n", pk_mi355_version());
@@ -114,6 +171,7 @@ int main(int argc, char **argv) {
   if (dir.back() != '/') dir += '/';
   TestFbankAndCmvn(dir);
   TestLinearLayerThroughDecodable();
+  TestPipelinedBatches(dir);
   printf("hot_path_test ok\n");
   return 0;
 }
