@@ -256,6 +256,8 @@ void LaunchTransposeToCols(const float *in, int64_t ld_in, int frames, int dim, 
 // exponentiate them and leave e in LDS, and a fifth wave -- lane = frame -- adds tile after
 // tile in column order, one tile behind the producers.  A second pass re-reads the logits
 // (the 64 x n block cannot stay on chip) and finishes every element in parallel.
+// (Measured alternative: two frames per workgroup with their exponentials kept in LDS -- one
+// pass over HBM, no second expf -- is slower, 4.3 vs 3.4 ms: its serial sum is exposed.)
 
 constexpr int kXRows = 64, kXCols = 64, kXLd = kXCols + 1;
 constexpr int kXProducers = 4;                         // waves; each owns 16 rows of a tile
