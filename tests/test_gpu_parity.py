@@ -665,3 +665,45 @@ def test_reference_softmax_whole_path_is_bit_identical_to_the_reference():
     for u, w in enumerate(waves):
         ref = nn.am_compute(O.cmvn(g, O.Fbank().compute(w)), prior, L, R, 0.1)
         assert bits_equal(bs.fetch(u).log_prob(), ref)
+
+
+# ------------------------------------------------------------------ seeded fuzz
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_ragged_batches_every_stage(seed, monkeypatch):
+    """Random ragged batches (lengths around the frame, CMVN-tile, window and chunk boundaries),
+    random chunk size and lane count, int16 or float ingestion: features bit-exact per utterance,
+    log-likelihoods bit-exact in reference-softmax mode and within the contract in the default mode."""
+    rng = np.random.default_rng(1000 + seed)
+    layers, prior, L, R, tid2pdf = tiny_model()
+    g = synth.global_cmvn_stats()
+    special = [0, 399, 400, 559, 560, 400 + 63 * 160, 400 + 64 * 160, 400 + 599 * 160, 400 + 600 * 160,
+               400 + 601 * 160, 400 + 639 * 160, 400 + 640 * 160]
+    lens = [int(special[rng.integers(len(special))] + rng.integers(0, 160) * rng.integers(0, 2)) for _ in range(5)]
+    lens += [int(rng.integers(0, 120000)) for _ in range(4)]
+    waves = [synth.utterance(500 + 16 * seed + i, seconds=8.0)[:n] for i, n in enumerate(lens)]
+    monkeypatch.setenv("PK_MI355_CHUNK", str(int(rng.choice([128, 384, 1024, 4096]))))
+    monkeypatch.setenv("PK_MI355_LANES", str(int(rng.choice([1, 2]))))
+    nn, fb = O.Nnet(layers), O.Fbank()
+    refs = []
+    for w in waves:
+        f = fb.compute(w)
+        c = O.cmvn(g, f)
+        refs.append((f, c, nn.am_compute(c, prior, L, R, 0.1) if len(f) else None))
+    for mode in ("reference", "stable"):
+        am = pk.AcousticModel(layers, prior, L, R, tid2pdf).set_softmax(mode)
+        bs = pk.BatchScorer(am, g, len(waves), max(sum(lens), 1))
+        if seed % 2:
+            bs.set_waves_i16([w.astype(np.int16) for w in waves])
+        else:
+            bs.set_waves(waves)
+        bs.score(0.1)
+        for u, (f, c, ll) in enumerate(refs):
+            assert bs.num_frames(u) == len(f)
+            if len(f) == 0:
+                continue
+            assert bits_equal(bs.fetch_fbank(u), f) and bits_equal(bs.fetch_cmvn(u), c)
+            got = bs.fetch(u).log_prob()
+            if mode == "reference":
+                assert bits_equal(got, ll)
+            else:
+                assert_loglik_close(got, ll)
