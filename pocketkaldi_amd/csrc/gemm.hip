@@ -27,6 +27,8 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "pk_kernels.h"
 
 #pragma clang fp contract(off)
@@ -200,11 +202,14 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
   __builtin_amdgcn_sched_barrier(0);
   read_frags(0, 0, fa_p, fa_q);
 
+  // The slabs that still have DMA to issue and the last kAhead ones run through two copies of
+  // the body, so that "is there a slab to fetch" is never a run-time predicate in the loop
+  // (hipcc turned it into vector compares that write a register the MFMAs are still reading).
   int slot = 0;
-  for (int kt = 0; kt < nkt; ++kt) {
+  auto slab_step = [&](int kt, auto dma_tag) {
+    constexpr bool dma = decltype(dma_tag)::value;
     int slot1 = slot + 1 == kRing ? 0 : slot + 1;
     int slot2 = slot == 0 ? kRing - 1 : slot - 1;     // slab kt + kAhead takes the slot of slab kt - 1
-    const bool dma = kt + kAhead < nkt;
 #pragma unroll
     for (int ks = 0; ks < kBK / 4; ++ks) {
       mfma_step(fa_p, fa_q, ks);
@@ -248,7 +253,10 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
     }
     __builtin_amdgcn_sched_barrier(0);
     slot = slot1;
-  }
+  };
+  int kt = 0;
+  for (; kt + kAhead < nkt; ++kt) slab_step(kt, std::true_type());
+  for (; kt < nkt; ++kt) slab_step(kt, std::false_type());
 
   if (KG > 1) {
     // every wave is past its last barrier, so no slab is read any more: the rings become the
