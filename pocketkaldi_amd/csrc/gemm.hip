@@ -202,6 +202,29 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
   __builtin_amdgcn_sched_barrier(0);
   read_frags(0, 0, fa_p, fa_q);
 
+  // In the loop the plain panels are addressed through running row pointers (scalar registers,
+  // one 64-bit add per piece and slab) instead of a 64-bit multiply per piece.
+  const char *prun[S], *qrun[S];
+#pragma unroll
+  for (int p = 0; p < S; ++p) {
+    const int64_t row = kAhead * kBK + wave * 4 + p * G::kPieceRows;
+    prun[p] = reinterpret_cast<const char *>(pg + row * a.ldp);
+    qrun[p] = reinterpret_cast<const char *>(qg + row * a.ldq);
+  }
+  const int64_t pstride = (int64_t)kBK * a.ldp * sizeof(float), qstride = (int64_t)kBK * a.ldq * sizeof(float);
+  auto issue_running = [&](int slot_to, int p) {
+    const int row = wave * 4 + (p < S ? p : p - S) * G::kPieceRows;
+    if (p < S) {
+      __builtin_amdgcn_global_load_lds((GlobalPtr)(prun[p] + lane_off_p),
+                                       (LdsPtr)(smem + (slot_to * 2 + 0) * kSlab + row * kBT), 16, 0, 0);
+      prun[p] += pstride;
+    } else {
+      __builtin_amdgcn_global_load_lds((GlobalPtr)(qrun[p - S] + lane_off_q),
+                                       (LdsPtr)(smem + (slot_to * 2 + 1) * kSlab + row * kBT), 16, 0, 0);
+      qrun[p - S] += qstride;
+    }
+  };
+
   // The slabs that still have DMA to issue and the last kAhead ones run through two copies of
   // the body, so that "is there a slab to fetch" is never a run-time predicate in the loop
   // (hipcc turned it into vector compares that write a register the MFMAs are still reading).
@@ -219,8 +242,10 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
       if (ks == 0) read_frags(slot, kBK / 4, fb_p, fb_q);
       if (dma) {
 #pragma unroll
-        for (int p = ks * kDma / 4; p < (ks + 1) * kDma / 4; ++p)
-          IssuePiece<S, SPLICE>(a, pg, qg, (kt + kAhead) * kBK, wave, lane, lane_off_p, lane_off_q, smem, slot2, p);
+        for (int p = ks * kDma / 4; p < (ks + 1) * kDma / 4; ++p) {
+          if (SPLICE && p >= S) IssuePiece<S, SPLICE>(a, pg, qg, (kt + kAhead) * kBK, wave, lane, lane_off_p, lane_off_q, smem, slot2, p);
+          else issue_running(slot2, p);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -236,6 +261,8 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
     __builtin_amdgcn_sched_barrier(0);
     read_frags(slot1, 0, fa_p, fa_q);   // unconditional (stale LDS on the last slab, unused): a branch
                                         // here makes hipcc wait lgkmcnt(0) ahead of the MFMAs below
+    asm volatile("" ::: "memory");      // keeps the reads HERE: LLVM otherwise sinks them to the end of
+                                        // the body, next to their first use
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < kBK / 4; ++ks) mfma_step(fb_p, fb_q, ks);
