@@ -45,6 +45,24 @@ constexpr int kThreads = 256;
 typedef const __attribute__((address_space(1))) void *GlobalPtr;
 typedef __attribute__((address_space(3))) void *LdsPtr;
 
+// LDS-DMA, 16 bytes per lane: LDS[m0 + lane * 16 ...] <- global.  Written as inline assembly so
+// that the scalar-base form can be used (wave-uniform 64-bit base in SGPRs + a 32-bit per-lane
+// byte offset: no vector address arithmetic); every DMA of this kernel goes through these two,
+// so M0 is never shared with compiler-generated LDS-DMA.
+__device__ __forceinline__ uint32_t LdsAddr(const float *p) {
+  return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p));     // low half of the flat address
+}
+__device__ __forceinline__ void DmaScalarBase(const float *lds_dst, const char *uniform_base, uint32_t lane_off) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               ::"s"(LdsAddr(lds_dst)), "v"(lane_off), "s"(uniform_base)
+               : "memory");
+}
+__device__ __forceinline__ void DmaVectorAddr(const float *lds_dst, const float *lane_ptr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               ::"s"(LdsAddr(lds_dst)), "v"(lane_ptr)
+               : "memory");
+}
+
 // Geometry for S x S MFMA tiles per wave (S = 2: 128 x 128 block tile, S = 1: 64 x 64).
 template <int S>
 struct Geo {
@@ -73,11 +91,11 @@ __device__ __forceinline__ void IssuePiece(const GemmArgs &a, const float *__res
   if (piece < S) {                                    // P rows
     const int row = wave * 4 + piece * G::kPieceRows; // wave-uniform
     const char *base = reinterpret_cast<const char *>(pg + (int64_t)(k0 + row) * a.ldp);
-    __builtin_amdgcn_global_load_lds((GlobalPtr)(base + lane_off_p), (LdsPtr)(ps + row * G::kBT), 16, 0, 0);
+    DmaScalarBase(ps + row * G::kBT, base, lane_off_p);
   } else if (!SPLICE) {                               // Q rows
     const int row = wave * 4 + (piece - S) * G::kPieceRows;
     const char *base = reinterpret_cast<const char *>(qg + (int64_t)(k0 + row) * a.ldq);
-    __builtin_amdgcn_global_load_lds((GlobalPtr)(base + lane_off_q), (LdsPtr)(qs + row * G::kBT), 16, 0, 0);
+    DmaScalarBase(qs + row * G::kBT, base, lane_off_q);
   } else {
     // am.cc:65-88 without materialising: operand row k is feature (k % D) of the
     // padded feature-major matrix, shifted by (k / D) frames.  The source is only
@@ -85,8 +103,7 @@ __device__ __forceinline__ void IssuePiece(const GemmArgs &a, const float *__res
     const int row = wave * 4 + (piece - S) * G::kPieceRows;
     const int k = k0 + row + lane / G::kLanesPerRow;
     const int c = k / a.splice_dim, d = k - c * a.splice_dim;
-    __builtin_amdgcn_global_load_lds((GlobalPtr)(qg + (int64_t)d * a.ldq + c + (lane % G::kLanesPerRow) * 4),
-                                     (LdsPtr)(qs + row * G::kBT), 16, 0, 0);
+    DmaVectorAddr(qs + row * G::kBT, qg + (int64_t)d * a.ldq + c + (lane % G::kLanesPerRow) * 4);
   }
 }
 
@@ -215,12 +232,10 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
   auto issue_running = [&](int slot_to, int p) {
     const int row = wave * 4 + (p < S ? p : p - S) * G::kPieceRows;
     if (p < S) {
-      __builtin_amdgcn_global_load_lds((GlobalPtr)(prun[p] + lane_off_p),
-                                       (LdsPtr)(smem + (slot_to * 2 + 0) * kSlab + row * kBT), 16, 0, 0);
+      DmaScalarBase(smem + (slot_to * 2 + 0) * kSlab + row * kBT, prun[p], lane_off_p);
       prun[p] += pstride;
     } else {
-      __builtin_amdgcn_global_load_lds((GlobalPtr)(qrun[p - S] + lane_off_q),
-                                       (LdsPtr)(smem + (slot_to * 2 + 1) * kSlab + row * kBT), 16, 0, 0);
+      DmaScalarBase(smem + (slot_to * 2 + 1) * kSlab + row * kBT, qrun[p - S], lane_off_q);
       qrun[p - S] += qstride;
     }
   };
