@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpk_mi355.so")
 HIP_SOURCES = ["frontend.hip", "gemm.hip", "gemm_f16.hip", "tail.hip", "capi.hip"]
 HOST_SOURCES = ["pk_tables.cc"]
-HEADERS = ["pk_kernels.h", "pk_tables.h", "pk_logf.h", os.path.join("..", "..", "include", "pk_mi355.h")]
+HEADERS = ["pk_kernels.h", "pk_tables.h", "pk_logf.h", "pk_expf.h", "pk_dma.h", os.path.join("..", "..", "include", "pk_mi355.h")]
 ARCH = "gfx950"
 
 

@@ -29,6 +29,7 @@
 
 #include <type_traits>
 
+#include "pk_dma.h"
 #include "pk_kernels.h"
 
 #pragma clang fp contract(off)
@@ -44,24 +45,6 @@ constexpr int kThreads = 256;
 
 typedef const __attribute__((address_space(1))) void *GlobalPtr;
 typedef __attribute__((address_space(3))) void *LdsPtr;
-
-// LDS-DMA, 16 bytes per lane: LDS[m0 + lane * 16 ...] <- global.  Written as inline assembly so
-// that the scalar-base form can be used (wave-uniform 64-bit base in SGPRs + a 32-bit per-lane
-// byte offset: no vector address arithmetic); every DMA of this kernel goes through these two,
-// so M0 is never shared with compiler-generated LDS-DMA.
-__device__ __forceinline__ uint32_t LdsAddr(const float *p) {
-  return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p));     // low half of the flat address
-}
-__device__ __forceinline__ void DmaScalarBase(const float *lds_dst, const char *uniform_base, uint32_t lane_off) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-               ::"s"(LdsAddr(lds_dst)), "v"(lane_off), "s"(uniform_base)
-               : "memory");
-}
-__device__ __forceinline__ void DmaVectorAddr(const float *lds_dst, const float *lane_ptr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-               ::"s"(LdsAddr(lds_dst)), "v"(lane_ptr)
-               : "memory");
-}
 
 // Geometry for S x S MFMA tiles per wave (S = 2: 128 x 128 block tile, S = 1: 64 x 64).
 template <int S>

@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
+#include "pk_dma.h"
 #include "pk_kernels.h"
 
 namespace pkmi {
@@ -98,21 +99,26 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
 
   // ---- DMA role of this lane: pieces 2 wave, 2 wave + 1 of X and of W; a piece is 16
   // LDS rows, lane -> row (lane >> 2), stored position (lane & 3)
-  const _Float16 *src[2][2];
+  // Source = wave-uniform base (SGPRs) + per-lane byte offset (32 bits): the rows of a piece
+  // differ by lane >> 2 only, and the W row -> column map is affine inside a piece.
+  const char *sbase[2][2];
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    const int row = (wave * 2 + p) * 16 + (lane >> 2);
-    const int q = (lane & 3) ^ ((row >> 2) & 3);    // logical position landing at this lane's slot
-    src[p][0] = a.X + (int64_t)(m0 + row) * a.ldx + q * 8;
-    src[p][1] = a.W + (int64_t)(n0 + WRowToCol(row)) * a.ldw + q * 8;
+    const int row0 = (wave * 2 + p) * 16;
+    sbase[p][0] = reinterpret_cast<const char *>(a.X + (int64_t)(m0 + row0) * a.ldx);
+    sbase[p][1] = reinterpret_cast<const char *>(a.W + (int64_t)(n0 + WRowToCol(row0)) * a.ldw);
   }
+  const int lr = lane >> 2;
+  const int q = (lane & 3) ^ ((lr >> 2) & 3);       // logical position landing at this lane's slot
+  const uint32_t voff[2] = {(uint32_t)(((int64_t)lr * a.ldx + q * 8) * sizeof(_Float16)),
+                            (uint32_t)(((int64_t)2 * lr * a.ldw + q * 8) * sizeof(_Float16))};
   auto issue_step = [&](int h, int slot) {          // k16 step h: 32 halves of every row
 #pragma unroll
     for (int op = 0; op < 2; ++op)
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         unsigned char *dst = smem + slot * kHalfSlabBytes + op * kOperandBytes + (wave * 2 + p) * 1024;
-        __builtin_amdgcn_global_load_lds((GlobalPtr)(src[p][op] + h * 32), (LdsPtr)dst, 16, 0, 0);
+        DmaScalarBase(reinterpret_cast<const float *>(dst), sbase[p][op] + h * 64, voff[op]);
       }
   };
 
