@@ -223,6 +223,35 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
     }
   };
 
+  // Spliced operand, 128-wide tiles: a piece is the two operand rows k, k + 1 = features
+  // (k % D, (k + 1) % D) of the padded feature-major matrix shifted by (k / D, (k + 1) / D) frames
+  // (am.cc:65-88).  The lower of the two row addresses is the scalar base, the other row's lanes
+  // carry the distance; (k % D, k / D) advance by 16 per slab without a division.
+  int sd[S], sc[S];
+  if (SPLICE && S == 2) {
+#pragma unroll
+    for (int p = 0; p < S; ++p) {
+      const int k = kAhead * kBK + wave * 4 + p * G::kPieceRows;
+      sc[p] = k / a.splice_dim;
+      sd[p] = k - sc[p] * a.splice_dim;
+    }
+  }
+  auto issue_splice = [&](int slot_to, int p) {       // p in [S, 2 S)
+    const int j = p - S;
+    const int row = wave * 4 + j * G::kPieceRows;
+    const int d0 = sd[j], c0 = sc[j];
+    const bool wrap = d0 + 1 == a.splice_dim;
+    const int64_t off0 = (int64_t)d0 * a.ldq + c0;
+    const int64_t off1 = wrap ? (int64_t)c0 + 1 : off0 + a.ldq;
+    const int64_t lo = off1 < off0 ? off1 : off0;
+    const uint32_t dist = (uint32_t)((off1 < off0 ? off0 - off1 : off1 - off0) * sizeof(float));
+    const bool second = lane >= G::kLanesPerRow;       // this lane fetches row k + 1
+    const uint32_t voff = (lane % G::kLanesPerRow) * 16 + ((second != (off1 < off0)) ? dist : 0u);
+    DmaScalarBase(smem + (slot_to * 2 + 1) * kSlab + row * kBT, reinterpret_cast<const char *>(qg + lo), voff);
+    sd[j] += kBK;
+    if (sd[j] >= a.splice_dim) { sd[j] -= a.splice_dim; ++sc[j]; }
+  };
+
   // The slabs that still have DMA to issue and the last kAhead ones run through two copies of
   // the body, so that "is there a slab to fetch" is never a run-time predicate in the loop
   // (hipcc turned it into vector compares that write a register the MFMAs are still reading).
@@ -241,7 +270,8 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
       if (dma) {
 #pragma unroll
         for (int p = ks * kDma / 4; p < (ks + 1) * kDma / 4; ++p) {
-          if (SPLICE && p >= S) IssuePiece<S, SPLICE>(a, pg, qg, (kt + kAhead) * kBK, wave, lane, lane_off_p, lane_off_q, smem, slot2, p);
+          if (SPLICE && p >= S && S == 2) issue_splice(slot2, p);
+          else if (SPLICE && p >= S) IssuePiece<S, SPLICE>(a, pg, qg, (kt + kAhead) * kBK, wave, lane, lane_off_p, lane_off_q, smem, slot2, p);
           else issue_running(slot2, p);
         }
       }
