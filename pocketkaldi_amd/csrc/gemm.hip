@@ -5,9 +5,10 @@
 //
 // Both operands are "k-major" panels (the output index is the contiguous one), so
 // a 16 x 128 slab of either is a set of 512-byte rows.  Slabs go HBM/L2 -> LDS by
-// LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write), the LDS image
-// [k][128] is read conflict-free by the MFMA operand pattern, nothing is ever
-// transposed.  Hidden layers run with P = W^T ([in][out]) and Q = activations
+// LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write) in its scalar-base
+// form (pk_dma.h: row base in SGPRs + a 32-bit lane offset; 64-bit per-lane addresses cost
+// 6 % of the kernel), the LDS image [k][128] is read conflict-free by the MFMA operand
+// pattern, nothing is ever transposed.  Hidden layers run with P = W^T ([in][out]) and Q = activations
 // ([feature][frame]) and store the next layer's [feature][frame] panel directly;
 // the last affine layer swaps the roles and stores frame-major rows for the softmax.
 //
@@ -23,7 +24,9 @@
 // (48 KiB) with two slabs of DMA in flight, one raw s_barrier per slab, three
 // workgroups per CU.  When a launch has too few 128 x 128 tiles to fill the chip
 // (a single utterance: 8 x 8 tiles for 256 CUs) the same kernel runs with 64 x 64
-// tiles (one MFMA tile per wave, S = 1) -- four times the workgroups.
+// tiles (one MFMA tile per wave, S = 1) -- four times the workgroups -- and, when k spans
+// 2..4 chunks of 512, with one group of four waves per chunk (KG) inside the workgroup.
+// The k-loop itself is straight-line code: no branches, no vector address arithmetic.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
