@@ -178,13 +178,11 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
     }
   };
   auto mfma_step = [&](const float (&pf)[kBK / 4][S], const float (&qf)[kBK / 4][S], int ks) {
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int x = 0; x < S; ++x)
 #pragma unroll
       for (int y = 0; y < S; ++y)
         acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[ks][x], qf[ks][y], acc[x][y], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- software pipeline.  Per slab kt (A = k-steps 0..3, B = k-steps 4..7):
