@@ -349,7 +349,8 @@ __global__ __launch_bounds__(64 * (kXProducers + 1)) void TailExactKernel(
 template <int MODE>
 static void LaunchTailMode(const float *in, int64_t ld_in, int rows, int n, const float *log_prior,
                            float scale, float *out, int64_t ld_out, hipStream_t stream) {
-  dim3 grid(rows < 4096 ? rows : 4096), block(kTailThreads);   // ~16 resident workgroups per CU
+  const int cap = 16384;   // measured: 4096 -> 1.08 ms, 16384 -> 1.00 ms, one row per workgroup -> 1.17 ms
+  dim3 grid(rows < cap ? rows : cap), block(kTailThreads);
   const int n4 = (n + 3) / 4;
   if (n4 <= kTailThreads)
     hipLaunchKernelGGL((TailKernel<MODE, 1>), grid, block, 0, stream, in, ld_in, rows, n, log_prior, scale, out, ld_out);
