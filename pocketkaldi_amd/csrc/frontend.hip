@@ -487,9 +487,9 @@ void LaunchFbank(const float *wave_f32, const int16_t *wave_i16, const UttLayout
                  int num_utts, int max_frames, const FrontendTables *d_tables, float *raw,
                  hipStream_t stream) {
   if (num_utts <= 0 || max_frames <= 0) return;
-  // ~6 workgroups per CU in flight; every wave then walks several frames, which
+  // ~12 workgroups per CU over the launch; every wave then walks several frames, which
   // amortises the table copy
-  int gx = 1536 / num_utts;
+  int gx = 3072 / num_utts;     // measured on 256 x 10 s: 1536 -> 0.57 ms, 3072 -> 0.51 ms, more: no change
   if (gx < 1) gx = 1;
   const int need = (max_frames + kFbankWaves - 1) / kFbankWaves;
   if (gx > need) gx = need;
