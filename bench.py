@@ -59,9 +59,38 @@ def cpu_baseline(model_name, seconds, num_utts):
         nn.am_compute(feats, prior, L, R, 0.1)
         frames += feats.shape[0]
     dt = time.perf_counter() - t0
-    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d utterances x %.0f s (%d frames), model %s, whole path, %.1f s of CPU"
-                      % (num_utts, seconds, frames, model_name, dt)}
+    out = {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d utterances x %.0f s (%d frames), model %s, whole path, %.1f s of CPU"
+                     % (num_utts, seconds, frames, model_name, dt)}
+    # The reference's own SGEMM (gemm.cc + gemm_haswell.cc, built into oracle/_ref/ where the
+    # reference tree was available) beside the port's, on the layer shapes of one utterance:
+    # the port is the thing timed above, this shows it runs at the reference kernel's speed.
+    try:
+        if O.have_ref():
+            rng = np.random.default_rng(0)
+            T = feats.shape[0]
+            shapes = [(l[1].shape[1], l[1].shape[0]) for l in layers if l[0] == "linear"]
+            flops, t_ref, t_port = 0.0, 0.0, 0.0
+            for K, N in shapes:
+                A = rng.standard_normal((T, K)).astype(np.float32)
+                B = rng.standard_normal((K, N)).astype(np.float32)
+                for fn, acc in ((O.ref_sgemm, "ref"), (O.sgemm, "port")):
+                    fn(A, B)
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        fn(A, B)
+                    d = (time.perf_counter() - t1) / 3
+                    if acc == "ref":
+                        t_ref += d
+                    else:
+                        t_port += d
+                flops += 2.0 * T * K * N
+            out["sgemm_gflops"] = {"reference_gemm_haswell": flops / t_ref / 1e9, "port": flops / t_port / 1e9,
+                                   "shapes": "T = %d rows through the %d affine layers of model %s, 1 core"
+                                             % (T, len(shapes), model_name)}
+    except Exception as e:          # the reference build is optional test infrastructure
+        out["sgemm_gflops"] = {"error": str(e)}
+    return out
 
 
 def cpu_baseline_all_cores(model_name, seconds, utts_per_thread):
