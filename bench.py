@@ -32,36 +32,41 @@ FP16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense
 
 
 def measured_traffic():
-    """HBM bytes per GEMM launch from the committed PMC passes (profiles/): bench.py cannot
-    run rocprofv3 around itself, so the number is the offline measurement of this same command."""
-    path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["gemm_avg_hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    """HBM bytes per GEMM launch from the newest committed PMC passes (profiles/rNN_pmc_traffic.json):
+    bench.py cannot run rocprofv3 around itself, so the number is the OFFLINE measurement of this
+    same command (tools/profile_gpu.sh), and the bench line says so in roofline.traffic_source."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                return json.load(f)["gemm_avg_hbm_bytes_per_launch"], os.path.relpath(path, REPO)
+        except Exception:
+            continue
+    return None, None
 
 
-def cpu_baseline(model_name, seconds, num_utts):
+def cpu_baseline(model_name, seconds, budget_s):
     """Oracle port (oracle/pk_oracle*.c: scalar fbank/CMVN + blocked AVX2 SGEMM of the
-    reference's class), ONE thread, on a bounded sample of the same workload."""
+    reference's class), ONE thread, on a sample of the same workload bounded by TIME: utterances
+    of the bench workload, in order, until budget_s seconds of CPU have been spent."""
     from oracle import oracle as O
     from pocketkaldi_amd import synth
     layers, prior, L, R = synth.model(model_name)
     nn = O.Nnet(layers)
     fb = O.Fbank()
     g = synth.global_cmvn_stats()
-    waves = [synth.utterance(u, seconds) for u in range(num_utts)]
-    frames = 0
-    t0 = time.perf_counter()
-    for w in waves:
+    frames, num_utts, dt = 0, 0, 0.0
+    while dt < budget_s and num_utts < 4096:
+        w = synth.utterance(num_utts, seconds)      # generation is not timed
+        t0 = time.perf_counter()
         feats = O.cmvn(g, fb.compute(w))
         nn.am_compute(feats, prior, L, R, 0.1)
+        dt += time.perf_counter() - t0
         frames += feats.shape[0]
-    dt = time.perf_counter() - t0
+        num_utts += 1
     out = {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": "%d utterances x %.0f s (%d frames), model %s, whole path, %.1f s of CPU"
-                     % (num_utts, seconds, frames, model_name, dt)}
+           "sample": "%d utterances x %.0f s (%d frames), model %s, whole path, %.1f s of CPU (time-capped at %.0f s)"
+                     % (num_utts, seconds, frames, model_name, dt, budget_s)}
     # The reference's own SGEMM (gemm.cc + gemm_haswell.cc, built into oracle/_ref/ where the
     # reference tree was available) beside the port's, on the layer shapes of one utterance:
     # the port is the thing timed above, this shows it runs at the reference kernel's speed.
@@ -93,9 +98,10 @@ def cpu_baseline(model_name, seconds, num_utts):
     return out
 
 
-def cpu_baseline_all_cores(model_name, seconds, utts_per_thread):
+def cpu_baseline_all_cores(model_name, seconds, budget_s):
     """the same port with utterance-level parallelism over the host cores
-    of this box's share (one oracle instance per thread; the C calls release the GIL)."""
+    of this box's share (one oracle instance per thread; the C calls release the GIL); every
+    thread works until budget_s seconds of wall time have passed."""
     import threading
     from oracle import oracle as O
     from pocketkaldi_amd import synth
@@ -103,27 +109,79 @@ def cpu_baseline_all_cores(model_name, seconds, utts_per_thread):
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("PK_BENCH_CPU_THREADS", "16")))
     layers, prior, L, R = synth.model(model_name)
     g = synth.global_cmvn_stats()
-    waves = [synth.utterance(u, seconds) for u in range(utts_per_thread)]
+    waves = [synth.utterance(u, seconds) for u in range(8)]
     frames = [0] * cores
     objs = [(O.Nnet(layers), O.Fbank()) for _ in range(cores)]
+    deadline = [0.0]
 
     def work(i):
         nn, fb = objs[i]
-        for w in waves:
-            feats = O.cmvn(g, fb.compute(w))
+        k = 0
+        while time.perf_counter() < deadline[0]:
+            feats = O.cmvn(g, fb.compute(waves[k % len(waves)]))
             nn.am_compute(feats, prior, L, R, 0.1)
             frames[i] += feats.shape[0]
+            k += 1
 
     th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
     t0 = time.perf_counter()
+    deadline[0] = t0 + budget_s
     for t in th:
         t.start()
     for t in th:
         t.join()
     dt = time.perf_counter() - t0
     return {"value": sum(frames) / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d threads x %d utterances x %.0f s (%d frames), model %s, whole path, %.1f s wall"
-                      % (cores, utts_per_thread, seconds, sum(frames), model_name, dt)}
+            "sample": "%d threads, %.0f s utterances (%d frames), model %s, whole path, %.1f s wall (time-capped at %.0f s)"
+                      % (cores, seconds, sum(frames), model_name, dt, budget_s)}
+
+
+def host_endpoints(pk, synth, am, batch, seconds, n_batches=8):
+    """SURVEY.md section 8d's two other end-points of the same workload (never `value`):
+      from_pinned_host : int16 PCM in page-locked host memory -> log-likelihoods complete in HBM;
+      host_complete    : ... -> every utterance's log_prob on the host as decoder.cc consumes it
+                         (pk_mi355_batch_fetch_all: one transfer per batch into a page-locked arena).
+    Two batches in flight: the upload of batch k+1 and the result transfer of batch k-1 run on
+    their own streams under the scoring of batch k."""
+    g = synth.global_cmvn_stats()
+    waves = [synth.utterance(u, seconds).astype(np.int16) for u in range(batch)]
+    ns = [len(w) for w in waves]
+    pin = pk.pinned_i16(int(sum(ns)))
+    pin[:] = np.concatenate(waves)
+    pair = [pk.BatchScorer(am, g, batch, int(sum(ns))) for _ in range(2)]
+    out = {}
+    for name, fetch in (("from_pinned_host", False), ("host_complete", True)):
+        for s_ in pair:                              # untimed: first use allocates buffers / the arena
+            s_.set_waves_i16_raw(pin, ns)
+            s_.score(0.1, sync=True)
+            if fetch:
+                s_.fetch_all()
+        t0 = time.perf_counter()
+        done = 0
+        busy = [False, False]
+        for k in range(n_batches + 2):
+            s_ = pair[k % 2]
+            if busy[k % 2]:
+                s_.synchronize()                     # scored (and, with fetch, on the host)
+                done += s_.total_frames()
+                busy[k % 2] = False
+            if k < n_batches:
+                s_.set_waves_i16_raw(pin, ns)        # H2D, 320 B/frame
+                s_.score(0.1, sync=False)
+                if fetch:
+                    s_.fetch_all(sync=False)         # D2H, 4 * num_pdfs B/frame
+                busy[k % 2] = True
+        dt = time.perf_counter() - t0
+        out[name] = {"value": done / dt, "unit": "frames/s", "ms_per_batch": dt / n_batches * 1e3,
+                     "batches": n_batches, "in_flight": 2}
+    out["from_pinned_host"]["start"] = "int16 PCM in page-locked host memory"
+    out["from_pinned_host"]["end"] = "log-likelihoods complete in HBM"
+    out["host_complete"]["start"] = "int16 PCM in page-locked host memory"
+    out["host_complete"]["end"] = "pk_decodable_t.log_prob of every utterance on the host (page-locked arena views)"
+    out["host_complete"]["d2h_gb_per_s"] = out["host_complete"]["value"] * 4.0 * am.num_pdfs() / 1e9
+    for s_ in pair:
+        s_.close()
+    return out
 
 
 def other_configs(pk, synth, torch, steps):
@@ -196,7 +254,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-precision", action="store_true",
                     help="skip the supplementary run in the other precision mode")
-    ap.add_argument("--cpu-utts", type=int, default=128, help="utterances in the CPU-baseline sample (~15 s of CPU)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="time cap of each CPU-baseline leg (1 thread, then all host cores), seconds")
+    ap.add_argument("--no-host-endpoints", action="store_true",
+                    help="skip the from_pinned_host / host_complete end-points (N = 1 only)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the supplementary BASELINE configs[1] / configs[4] lines (N = 1 only)")
     args = ap.parse_args()
@@ -229,11 +290,7 @@ def main():
         prior = np.full_like(prior, 1.0)
     am = pk.AcousticModel(layers, prior, L, R, precision=args.precision).set_softmax(args.softmax)
     import torch.distributed as tdist
-    if world > 1 or tdist.is_initialized():
-        ptr, nbytes = am.blob()
-        blob = pkdist.alias_device_bytes(ptr, nbytes, dev)
-        pkdist.broadcast_blob(blob, src=0)          # the one RCCL collective of the path
-        torch.cuda.synchronize()
+    pkdist.broadcast_model(am, dev, src=0)          # the one RCCL collective of the path (no-op at world 1)
 
     # ---- synthetic PCM, resident in HBM before any timed region
     ids = pkdist.utterance_ids(rank, world, args.batch)
@@ -280,10 +337,7 @@ def main():
         other_prec = "f16x3" if args.precision == "f32" else "f32"
         bs.close()
         am2 = pk.AcousticModel(layers, prior, L, R, precision=other_prec).set_softmax(args.softmax)
-        if world > 1 or tdist.is_initialized():
-            ptr2, nbytes2 = am2.blob()
-            pkdist.broadcast_blob(pkdist.alias_device_bytes(ptr2, nbytes2, dev), src=0)
-            torch.cuda.synchronize()
+        pkdist.broadcast_model(am2, dev, src=0)
         bs2 = pk.BatchScorer(am2, synth.global_cmvn_stats(), args.batch, int(sum(ns)))
         bs2.set_waves_device(pcm.data_ptr(), ns, keep_alive=pcm)
         dt2, tm2 = timed_steps(bs2)
@@ -338,7 +392,7 @@ def main():
                          "frac": achieved / peak,
                          "flop_per_frame": am.flops_per_frame(),
                          "kernel_ms_per_step": gemm_ms,
-                         "algorithmic_bytes_per_launch": None, "traffic": None},
+                         "algorithmic_bytes_per_launch": None, "traffic": None, "traffic_source": None},
             "stage_ms_per_step": {k: tm[k][0] for k in pk.KINDS},
         }
         if other is not None:
@@ -356,19 +410,28 @@ def main():
             out["stage_roofline"][k] = {"bound": "hbm", "bytes_per_frame": bpf, "achieved": gbs,
                                         "peak": hbm_peak, "unit": "GB/s", "frac": gbs / hbm_peak}
         if args.model == "S" and args.batch == 256 and gemm_launches and args.precision == "f32":
-            out["roofline"]["traffic"] = measured_traffic()
+            traffic, source = measured_traffic()
+            out["roofline"]["traffic"] = traffic
+            out["roofline"]["traffic_source"] = None if source is None else (
+                "%s (offline rocprofv3 PMC passes of this command, FETCH_SIZE x 2 + WRITE_SIZE per launch; not measured in this run)" % source)
             # operands read once + output written once, averaged over the launches of a step
             # (layer 1 reads the 40-dim features, the splice is a view)
             lay = [(40, 440, 1024)] + [(1024, 1024, 1024)] * 3 + [(1024, 1024, 3000)]
             rows = frames_per_step + 10 * args.batch
             out["roofline"]["algorithmic_bytes_per_launch"] = (
                 sum(4.0 * (rows * kin + k * n + rows * n) for kin, k, n in lay) / gemm_launches)
+        if world == 1 and not args.no_host_endpoints and args.precision == "f32":
+            bs.close()
+            out["endpoints"] = {"device_complete": {"value": value, "unit": "frames/s",
+                                                    "start": "float PCM resident in HBM", "end": "log-likelihoods complete in HBM",
+                                                    "note": "= value, the headline"}}
+            out["endpoints"].update(host_endpoints(pk, synth, am, args.batch, args.seconds))
         if world == 1 and not args.no_other_configs:
             bs.close()
             out["other_configs"] = other_configs(pk, synth, torch, max(2, min(args.steps, 3)))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.model, args.seconds, args.cpu_utts)
-            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.model, args.seconds, 32)
+            out["cpu_baseline"] = cpu_baseline(args.model, args.seconds, args.cpu_seconds)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.model, args.seconds, min(args.cpu_seconds, 8.0))
         print(json.dumps(out), flush=True)
     pkdist.barrier()
     bs.close()

@@ -71,8 +71,15 @@ enum {
 
 const char *pk_mi355_last_error(void);
 
-/* Select the HIP device used by subsequently created objects (default 0).
- * One process drives one GPU (one rank per GPU in multi-GPU runs).               */
+/* Select the HIP device used by objects this THREAD creates afterwards (default 0; like
+ * hipSetDevice the setting is per host thread).  One process drives one GPU (one rank per GPU
+ * in multi-GPU runs).
+ *
+ * Threads: a model may be shared by host threads.  pk_decodable_init, pk_mi355_nnet_propagate and
+ * pk_mi355_process_acoustic use one device workspace per model and serialise on a per-model lock
+ * (the reference's versions allocate per call, nnet.cc:149-163); the four pk_decodable_* readers
+ * are lock-free.  A pk_mi355_batch_t belongs to one thread at a time; different batches of one
+ * model may be driven from different threads.                                                 */
 int pk_mi355_set_device(int device);
 
 /* ------------------------------------------------------------------------- */
@@ -157,6 +164,16 @@ int pk_mi355_am_transition_to_pdf(const pk_mi355_am_t *am, int trans_id); /* am.
  * holds the real values, all ranks broadcast [ptr, ptr+bytes) from rank 0.       */
 void *pk_mi355_am_blob_device_ptr(pk_mi355_am_t *am);
 size_t pk_mi355_am_blob_bytes(const pk_mi355_am_t *am);
+/* That broadcast, for a C/C++ host (the multi-GPU form of pk_load, pocketkaldi.cc:72-144): ONE
+ * ncclBroadcast of the blob from rank `root` into every rank's blob, in place, over the caller's
+ * RCCL communicator.  rccl_comm: the caller's ncclComm_t (one process per GPU, the communicator's
+ * device is the model's device).  stream: a hipStream_t to enqueue on (the caller synchronises it
+ * before scoring), or NULL: the call then uses a stream of its own and returns when the
+ * broadcast has completed.  tid2pdf and the layer structure are host-side and are NOT sent: every
+ * rank reads the (small) tid2pdf file itself or builds the same structure, as bench.py does.
+ * RCCL is bound at run time from the process (the copy the communicator was created with), or
+ * from librccl.so.1 / $PK_MI355_RCCL_LIB: libpk_mi355.so has no link-time dependency on it.     */
+int pk_mi355_am_broadcast(pk_mi355_am_t *am, void *rccl_comm, int root, void *stream);
 
 /* Nnet::Propagate, nnet.cc:149-163: in {ncol = T, nrow = in_dim} host ->
  * out {ncol = T, nrow = out_dim} host (out->data is (re)allocated with malloc). */
@@ -221,10 +238,13 @@ int pk_mi355_batch_fetch(pk_mi355_batch_t *b, int utt, pk_decodable_t *out);
  * (made on first use), and out[0..num_out) (num_out == pk_mi355_batch_num_utts) filled as
  * decodables whose log_prob VIEWS that arena -- same fields, same [T][num_pdfs] layout, usable
  * by Decoder::Decode like any other (decoder.cc:39).  pk_decodable_destroy on such a view
- * frees nothing, and must happen (if at all) before the batch is destroyed.  The views are
- * valid until the batch is scored again or destroyed.  With
- * sync == 0 the copy is queued on the batch's stream (after the scoring it follows) and
- * pk_mi355_batch_synchronize completes it, so it overlaps another batch's scoring.          */
+ * frees nothing of the caller's and may happen at any time, also after pk_mi355_batch_destroy
+ * (pocketkaldi.cc:247 destroys its decodable unconditionally): the arena is released when the
+ * batch is gone AND the views of its last fetch_all have been destroyed.  The CONTENTS of the views
+ * are valid until the batch is scored again or destroyed.  With sync == 0 the copy is queued on
+ * the device's result stream, ordered after this batch's scoring and before anything queued
+ * later on the batch's stream; pk_mi355_batch_synchronize completes it, so it overlaps another
+ * batch's scoring.                                                                           */
 int pk_mi355_batch_fetch_all(pk_mi355_batch_t *b, pk_decodable_t *out, int num_out, int sync);
 /* Intermediate stages, for parity tests: raw fbank / CMVN'd features of utt,
  * copied to host as [T][40].                                                     */
@@ -233,6 +253,10 @@ int pk_mi355_batch_fetch_cmvn(pk_mi355_batch_t *b, int utt, float *out);
 /* Parity-test hook: the front-end's logf (fbank.cc:244-245 -> vector.cc:334-339 -> libm logf,
  * restated for the device in csrc/pk_logf.h) on n host floats (positive normal, +inf or NaN).  */
 int pk_mi355_test_logf(const float *x, int n, float *out);
+/* Parity-test hook: the front-end's 512-point real FFT alone -- pk_srfft_compute (srfft.cc:371-461,
+ * forward) as FbankKernel runs it, on num_frames host frames of 512 floats; spectra receives the
+ * reference's packed layout [Re0+Im0, Re0-Im0, Re1, Im1, ..., Re255, Im255] per frame.            */
+int pk_mi355_test_srfft512(const float *frames, int num_frames, float *spectra);
 
 /* Device-side pk_decodable_loglikelihood (decodable.cc:24-31) for a GPU-resident consumer
  * (decoder.cc:252-279 evaluates one (frame, transition-id) pair per arc): n pairs in

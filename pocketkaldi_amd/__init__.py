@@ -62,6 +62,7 @@ EXPORTS = [
     "pk_mi355_batch_score", "pk_mi355_batch_synchronize", "pk_mi355_batch_num_utts",
     "pk_mi355_batch_num_frames", "pk_mi355_batch_total_frames", "pk_mi355_batch_loglik_device",
     "pk_mi355_batch_fetch", "pk_mi355_batch_fetch_all", "pk_mi355_batch_fetch_fbank", "pk_mi355_batch_fetch_cmvn", "pk_mi355_test_logf",
+    "pk_mi355_test_srfft512", "pk_mi355_am_broadcast",
     "pk_mi355_batch_gather_loglik", "pk_mi355_device_malloc", "pk_mi355_device_free", "pk_mi355_memcpy",
     "pk_mi355_host_malloc", "pk_mi355_host_free",
     "pk_mi355_batch_stream", "pk_mi355_batch_enable_timing", "pk_mi355_batch_get_timing",
@@ -71,21 +72,26 @@ EXPORTS = [
 
 
 def lib_path():
-    # PK_MI355_LIB: developer override (A/B builds of the kernels); the product is the in-tree library
-    return os.environ.get("PK_MI355_LIB") or os.path.join(_HERE, "libpk_mi355.so")
+    """The product library: always the in-tree build."""
+    return os.path.join(_HERE, "libpk_mi355.so")
 
 
 def lib():
-    """Load libpk_mi355.so (building it in-tree first if the sources are newer)."""
+    """Load libpk_mi355.so, (re)building it in-tree first whenever the sources it was built from
+    differ from the sources in the tree (content hash, build.py).  A stale library is never
+    loaded silently: where no compiler exists the load fails instead."""
     global _lib
     if _lib is not None:
         return _lib
     path = lib_path()
-    if not os.path.exists(path):
+    if _build._stale():
+        if not _build.have_compiler():
+            raise PkError("libpk_mi355.so is %s and there is no hipcc here to build it"
+                          % ("stale (sources changed since it was built)" if os.path.exists(path) else "missing"))
         try:
             _build.build()
-        except Exception as e:   # no hipcc on this machine and no prebuilt library
-            raise PkError("libpk_mi355.so is missing and cannot be built: %s" % e)
+        except Exception as e:
+            raise PkError("libpk_mi355.so cannot be built: %s" % e)
     L = C.CDLL(path)
     f32p, i32p = C.POINTER(C.c_float), C.POINTER(C.c_int32)
     L.pk_mi355_last_error.restype = C.c_char_p
@@ -148,6 +154,8 @@ def lib():
     L.pk_mi355_batch_fetch_fbank.argtypes = [C.c_void_p, C.c_int, f32p]
     L.pk_mi355_batch_fetch_cmvn.argtypes = [C.c_void_p, C.c_int, f32p]
     L.pk_mi355_test_logf.argtypes = [f32p, C.c_int, f32p]
+    L.pk_mi355_test_srfft512.argtypes = [f32p, C.c_int, f32p]
+    L.pk_mi355_am_broadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.pk_mi355_batch_gather_loglik.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.pk_mi355_device_malloc.restype = C.c_void_p
     L.pk_mi355_device_malloc.argtypes = [C.c_size_t]
@@ -347,6 +355,11 @@ class AcousticModel:
         """(device pointer, bytes) of the packed weights, for the RCCL broadcast."""
         return lib().pk_mi355_am_blob_device_ptr(self._h), lib().pk_mi355_am_blob_bytes(self._h)
 
+    def broadcast(self, rccl_comm, root=0, stream=None):
+        """pk_mi355_am_broadcast: one ncclBroadcast of the blob over the caller's ncclComm_t (an integer handle)."""
+        _check(lib().pk_mi355_am_broadcast(self._h, C.c_void_p(rccl_comm), int(root),
+                                           None if stream is None else C.c_void_p(stream)))
+
     def propagate(self, x):
         """Nnet::Propagate (nnet.cc:149-163): x [T][in_dim] -> [T][out_dim]."""
         x = _f32(x)
@@ -361,6 +374,14 @@ def device_logf(x):
     x = _f32(x).ravel()
     out = np.empty_like(x)
     _check(lib().pk_mi355_test_logf(_fp(x), x.shape[0], _fp(out)))
+    return out
+
+
+def device_srfft512(frames):
+    """The front-end kernel's 512-point real FFT on [n][512] frames (parity-test hook)."""
+    x = _f32(frames).reshape(-1, 512)
+    out = np.empty_like(x)
+    _check(lib().pk_mi355_test_srfft512(_fp(x), x.shape[0], _fp(out)))
     return out
 
 

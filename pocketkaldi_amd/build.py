@@ -5,7 +5,13 @@
 hipcc cross-compiles without a GPU.  Device and host float code is compiled with
 -ffp-contract=off: parity with the reference depends on a*b+c NOT being fused
 where the reference's x86-64 build does not fuse (see csrc/frontend.hip).
+
+Staleness is decided by CONTENT, not by mtime: the hash of every source and header is
+written next to the library (libpk_mi355.buildhash) and compared on every load, so a
+prebuilt library that travelled with the tree (the .so is git-ignored but ships to the GPU
+box) can never be loaded against newer sources without a rebuild.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -13,44 +19,72 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpk_mi355.so")
+STAMP = os.path.join(HERE, "libpk_mi355.buildhash")
 HIP_SOURCES = ["frontend.hip", "gemm.hip", "gemm_f16.hip", "tail.hip", "capi.hip"]
 HOST_SOURCES = ["pk_tables.cc"]
-HEADERS = ["pk_kernels.h", "pk_tables.h", "pk_logf.h", "pk_expf.h", "pk_dma.h", os.path.join("..", "..", "include", "pk_mi355.h")]
+HEADERS = ["pk_kernels.h", "pk_tables.h", "pk_logf.h", "pk_expf.h", "pk_dma.h",
+           os.path.join("..", "..", "include", "pk_mi355.h")]
 ARCH = "gfx950"
+HIP_FLAGS = ["--offload-arch=" + ARCH, "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-Wall",
+             "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+HOST_FLAGS = ["-std=c++17", "-O2", "-ffp-contract=off", "-fPIC"]
+# RCCL is bound at run time (dlopen in capi.hip): the library has no link-time dependency on it
+LINK_LIBS = ["-ldl"]
+
+
+def source_hash():
+    h = hashlib.sha256()
+    for s in HIP_SOURCES + HOST_SOURCES + HEADERS:
+        with open(os.path.join(CSRC, s), "rb") as f:
+            h.update(s.encode() + b"\0" + f.read() + b"\0")
+    h.update(" ".join(HIP_FLAGS + HOST_FLAGS + LINK_LIBS).encode())
+    return h.hexdigest()
 
 
 def _stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in HIP_SOURCES + HOST_SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != source_hash()
+
+
+def have_compiler():
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    return os.path.exists(hipcc)
 
 
 def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    digest = source_hash()
     objs = []
     for s in HOST_SOURCES:
         o = os.path.join(CSRC, s + ".o")
-        cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = ["g++"] + HOST_FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(o)
-    for s in HIP_SOURCES:
+    procs = []
+    for s in HIP_SOURCES:                       # the five translation units are independent
         o = os.path.join(CSRC, s + ".o")
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC",
-               "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc] + HIP_FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        procs.append((cmd, subprocess.Popen(cmd)))
         objs.append(o)
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    tmp = LIB + ".tmp"
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs + LINK_LIBS
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)
+    with open(STAMP, "w") as f:
+        f.write(digest + "\n")
     return LIB
 
 

@@ -3,6 +3,7 @@
 // pk_decodable_* functions.  Host C++ over the HIP runtime; no CPU compute path.
 #include <hip/hip_runtime.h>
 #include <ctype.h>
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -26,7 +27,9 @@ using namespace pkmi;
 namespace {
 
 thread_local char g_err[512] = "";
-int g_device = 0;
+// Like hipSetDevice, the selected device is a per-thread setting (a worker thread that never
+// called pk_mi355_set_device creates its objects on device 0).
+thread_local int g_device = 0;
 
 int Fail(int code, const char *fmt, ...) {
   va_list ap;
@@ -176,8 +179,12 @@ struct pk_mi355_am {
   size_t blob_floats = 0;
   size_t logprior_off = 0;
   double flops_per_frame = 0;
-  Workspace *ws = nullptr;         // single-utterance workspace of pk_decodable_init
-  struct pk_mi355_batch *proc = nullptr;   // cached 1-utterance scorer of pk_mi355_process_acoustic
+  // The reference's pk_decodable_init / AcousticModel::Compute allocate per call and are re-entrant
+  // for a shared model (nnet.cc:149-163 is const); here the single-utterance entry points share
+  // one device workspace per model, so they serialise on this mutex instead.
+  std::mutex mu;
+  Workspace *ws = nullptr;         // single-utterance workspace of pk_decodable_init (under mu)
+  struct pk_mi355_batch *proc = nullptr;   // cached 1-utterance scorer of pk_mi355_process_acoustic (under mu)
   int64_t proc_cap = 0;
   float proc_stats[41] = {0};
 };
@@ -339,7 +346,6 @@ int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t
       case PK_NNET_SOFTMAX_LAYER: {
         if (cur_splice) return Fail(PK_MI355_E_INVALID, "network must start with a linear layer when splicing");
         if (!cur_rows) to_rows();
-        if (cur_dim > 8192) return Fail(PK_MI355_E_INVALID, "softmax wider than 8192 is not supported");
         const bool final_layer = (i == nl - 1);
         Scoped t(timer, PK_MI355_K_TAIL, stream);
         if (final_layer && want_tail) {
@@ -363,7 +369,6 @@ int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t
     to_rows();
   }
   if (want_tail && !tail_done) {
-    if (cur_dim > 8192) return Fail(PK_MI355_E_INVALID, "output wider than 8192 is not supported");
     Scoped t(timer, PK_MI355_K_TAIL, stream);
     LaunchTail(kTailLoglik, am->softmax_reference, cur, cur_ld, rows, cur_dim, blob + am->logprior_off,
                scale, tail_out, tail_ld, stream);
@@ -512,20 +517,63 @@ int ResizeHostMatrix(pk_matrix_t *m, int nrow, int ncol) {
 
 // ================================================================== C ABI
 
-// Page-locked host arenas of live batches (pk_mi355_batch_fetch_all): pk_decodable_destroy must
-// not free() a pointer into one of them.
+// Page-locked host arenas of pk_mi355_batch_fetch_all.  A decodable handed out by fetch_all is a
+// VIEW into its batch's arena; pk_decodable_destroy must not free() such a pointer, and the
+// reference's caller destroys its decodable unconditionally, whenever it likes
+// (pocketkaldi.cc:247) -- also after the batch is gone.  So the arena is shared property: it
+// counts the views handed out by the last fetch_all, and the page-locked memory is released when
+// the batch has been destroyed AND the last of those views has been destroyed, whichever comes
+// last.  (A caller that never destroys its views keeps the arena until the process ends.)
 namespace {
 std::mutex g_arena_mu;
-std::vector<std::pair<const char *, const char *>> g_arenas;
+struct Arena {
+  char *lo, *hi;
+  int live_views;      // views of the last fetch_all not yet destroyed
+  bool batch_alive;
+};
+std::vector<Arena> g_arenas;
 
-void RegisterArena(const void *p, size_t bytes) {
+void RegisterArena(void *p, size_t bytes) {
   std::lock_guard<std::mutex> g(g_arena_mu);
-  g_arenas.emplace_back(static_cast<const char *>(p), static_cast<const char *>(p) + bytes);
+  g_arenas.push_back(Arena{static_cast<char *>(p), static_cast<char *>(p) + bytes, 0, true});
 }
-void UnregisterArena(const void *p) {
+void SetArenaViews(const void *p, int views) {
   std::lock_guard<std::mutex> g(g_arena_mu);
-  for (size_t i = 0; i < g_arenas.size(); ++i)
-    if (g_arenas[i].first == p) { g_arenas.erase(g_arenas.begin() + i); return; }
+  for (auto &a : g_arenas)
+    if (a.lo == p) a.live_views = views;
+}
+// The batch is going away: release the arena now, or leave that to the last view.
+void RetireArena(void *p) {
+  bool release = false;
+  {
+    std::lock_guard<std::mutex> g(g_arena_mu);
+    for (size_t i = 0; i < g_arenas.size(); ++i)
+      if (g_arenas[i].lo == p) {
+        g_arenas[i].batch_alive = false;
+        if (g_arenas[i].live_views <= 0) { g_arenas.erase(g_arenas.begin() + i); release = true; }
+        break;
+      }
+  }
+  if (release) hipHostFree(p);
+}
+// pk_decodable_destroy on `p`: true if p points into an arena (then nothing may be free()d).
+bool ReleaseArenaView(const void *p) {
+  if (!p) return false;
+  void *release = nullptr;
+  bool found = false;
+  {
+    std::lock_guard<std::mutex> g(g_arena_mu);
+    for (size_t i = 0; i < g_arenas.size(); ++i) {
+      Arena &a = g_arenas[i];
+      if (static_cast<const char *>(p) < a.lo || static_cast<const char *>(p) >= a.hi) continue;
+      found = true;
+      if (a.live_views > 0) --a.live_views;
+      if (!a.batch_alive && a.live_views == 0) { release = a.lo; g_arenas.erase(g_arenas.begin() + i); }
+      break;
+    }
+  }
+  if (release) hipHostFree(release);
+  return found;
 }
 // One device-to-host result stream per device (pk_mi355_batch_fetch_all); lives for the process.
 hipStream_t ResultStream(int device) {
@@ -537,13 +585,6 @@ hipStream_t ResultStream(int device) {
     if (e != hipSuccess) { Fail(PK_MI355_E_DEVICE, "result stream: %s", hipGetErrorString(e)); return nullptr; }
   }
   return streams[device];
-}
-bool IsArenaPointer(const void *p) {
-  if (!p) return false;
-  std::lock_guard<std::mutex> g(g_arena_mu);
-  for (const auto &a : g_arenas)
-    if (static_cast<const char *>(p) >= a.first && static_cast<const char *>(p) < a.second) return true;
-  return false;
 }
 }  // namespace
 
@@ -912,12 +953,71 @@ void *pk_mi355_am_blob_device_ptr(pk_mi355_am_t *am) { return am ? am->d_blob : 
 size_t pk_mi355_am_blob_bytes(const pk_mi355_am_t *am) { return am ? am->blob_floats * sizeof(float) : 0; }
 double pk_mi355_am_flops_per_frame(const pk_mi355_am_t *am) { return am ? am->flops_per_frame : 0; }
 
+// ---- the one collective of the path: weight-blob broadcast over the caller's RCCL communicator.
+// RCCL's C API, bound at run time (rccl.h: ncclBroadcast, ncclGetErrorString; ncclUint8 = 1).
+namespace {
+typedef int (*NcclBroadcastFn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef const char *(*NcclErrorStringFn)(int);
+std::mutex g_rccl_mu;
+NcclBroadcastFn g_nccl_broadcast = nullptr;
+NcclErrorStringFn g_nccl_error_string = nullptr;
+
+int BindRccl() {
+  std::lock_guard<std::mutex> g(g_rccl_mu);
+  if (g_nccl_broadcast) return 0;
+  // the copy already in the process first: the communicator belongs to it
+  void *sym = dlsym(RTLD_DEFAULT, "ncclBroadcast");
+  void *h = nullptr;
+  if (!sym) {
+    const char *path = getenv("PK_MI355_RCCL_LIB");
+    h = dlopen(path ? path : "librccl.so.1", RTLD_NOW | RTLD_LOCAL);   // an already loaded copy is matched by soname
+    if (!h && !path) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return Fail(PK_MI355_E_DEVICE, "RCCL is not loaded and cannot be opened: %s", dlerror());
+    sym = dlsym(h, "ncclBroadcast");
+  }
+  if (!sym) return Fail(PK_MI355_E_DEVICE, "ncclBroadcast not found in RCCL");
+  void *es = h ? dlsym(h, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString");
+  g_nccl_error_string = reinterpret_cast<NcclErrorStringFn>(es);
+  g_nccl_broadcast = reinterpret_cast<NcclBroadcastFn>(sym);
+  return 0;
+}
+}  // namespace
+
+int pk_mi355_am_broadcast(pk_mi355_am_t *am, void *rccl_comm, int root, void *stream) {
+  if (!am || !am->finalized) return Fail(PK_MI355_E_STATE, "model not finalized");
+  if (!rccl_comm) return Fail(PK_MI355_E_INVALID, "null RCCL communicator");
+  if (root < 0) return Fail(PK_MI355_E_INVALID, "bad root rank %d", root);
+  int rc = UseDevice(am->device);
+  if (rc || (rc = BindRccl())) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipStream_t own = nullptr;
+  if (!s) {
+    HIP_TRY(hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
+    s = own;
+  }
+  // in place: send buffer = receive buffer = this rank's blob (same size on every rank: the
+  // layout depends on the layer structure only)
+  const int nr = g_nccl_broadcast(am->d_blob, am->d_blob, am->blob_floats * sizeof(float), /*ncclUint8*/ 1, root,
+                                  rccl_comm, s);
+  if (nr != 0) {
+    if (own) hipStreamDestroy(own);
+    return Fail(PK_MI355_E_DEVICE, "ncclBroadcast failed: %s", g_nccl_error_string ? g_nccl_error_string(nr) : "?");
+  }
+  if (own) {
+    hipError_t e = hipStreamSynchronize(own);
+    hipStreamDestroy(own);
+    if (e != hipSuccess) return Fail(PK_MI355_E_DEVICE, "broadcast stream: %s", hipGetErrorString(e));
+  }
+  return 0;
+}
+
 int pk_mi355_nnet_propagate(pk_mi355_am_t *am, const pk_matrix_t *in, pk_matrix_t *out) {
   if (!am || !am->finalized) return Fail(PK_MI355_E_STATE, "model not finalized");
   if (!in || !out || in->nrow != am->input_dim)
     return Fail(PK_MI355_E_INVALID, "input has %d rows, the network expects %d", in ? in->nrow : -1, am->input_dim);
   int rc = UseDevice(am->device);
   if (rc) return rc;
+  std::lock_guard<std::mutex> lock(am->mu);
   const int T = in->ncol, D = in->nrow;
   if ((rc = ResizeHostMatrix(out, am->output_dim, T))) return rc;
   if (T == 0) return 0;
@@ -960,13 +1060,20 @@ void pk_decodable_init(pk_decodable_t *self, pk_mi355_am_t *am, float prob_scale
   if (UseDevice(am->device)) return;
   const int T = feats->ncol, D = feats->nrow, N = am->num_pdfs;
   if (T <= 0) return;
+  const bool f16 = am->precision == PK_MI355_PRECISION_F16X3;
+  if (f16 && D % 8 != 0) {
+    // the interleaved (hi, lo) row of a frame is made of whole 8-k chunks: the spliced view
+    // (row stride 2 D halves, gemm_f16.hip) exists only for such D
+    Fail(PK_MI355_E_INVALID, "f16x3 precision needs a feature dimension that is a multiple of 8 (got %d)", D);
+    return;
+  }
+  std::lock_guard<std::mutex> lock(am->mu);
   if (EnsureWorkspace(am, T, D)) return;
   Workspace *w = am->ws;
   auto dev_fail = [&](hipError_t e) { Fail(PK_MI355_E_DEVICE, "HIP failure in pk_decodable_init: %s", hipGetErrorString(e)); };
   hipError_t e = hipMemcpyAsync(w->d_feats, feats->data, sizeof(float) * (size_t)T * D, hipMemcpyHostToDevice, w->stream);
   if (e != hipSuccess) { dev_fail(e); return; }
   LaunchPadTranspose(w->d_feats, T, D, am->left, am->right, w->d_yt, w->yt_ld, 0, w->stream);
-  const bool f16 = am->precision == PK_MI355_PRECISION_F16X3;
   if (f16) LaunchSplitF16(w->d_yt, 1, w->yt_ld, (int)w->yt_ld, D, D, w->d_y2, 2 * D, w->stream);
   for (int64_t r0 = 0; r0 < T; r0 += kSingleChunk) {
     const int rows = (int)std::min<int64_t>(kSingleChunk, T - r0);
@@ -989,7 +1096,7 @@ void pk_decodable_init(pk_decodable_t *self, pk_mi355_am_t *am, float prob_scale
 void pk_decodable_destroy(pk_decodable_t *self) {
   // matrix.cc:123-128 frees; a decodable handed out by pk_mi355_batch_fetch_all is a view of
   // the batch's page-locked arena and owns nothing.
-  if (!IsArenaPointer(self->log_prob.data)) free(self->log_prob.data);
+  if (!ReleaseArenaView(self->log_prob.data)) free(self->log_prob.data);
   self->log_prob.data = nullptr;
   self->log_prob.nrow = 0;
   self->log_prob.ncol = 0;
@@ -1173,7 +1280,7 @@ void pk_mi355_batch_destroy(pk_mi355_batch_t *b) {
   hipFree(b->d_wave); hipFree(b->d_wave_i16);
   hipFree(b->d_wave_off); hipFree(b->d_raw_base); hipFree(b->d_pad_base); hipFree(b->d_T);
   hipFree(b->d_raw); hipFree(b->d_yt); hipFree(b->d_y2); hipFree(b->d_ll);
-  if (b->h_ll) { UnregisterArena(b->h_ll); hipHostFree(b->h_ll); }
+  if (b->h_ll) RetireArena(b->h_ll);     // released now, or by the last outstanding view
   if (b->ev_scored) hipEventDestroy(b->ev_scored);
   if (b->ev_fetched) hipEventDestroy(b->ev_fetched);
   if (b->stream) hipStreamDestroy(b->stream);
@@ -1343,13 +1450,16 @@ int pk_mi355_batch_fetch_all(pk_mi355_batch_t *b, pk_decodable_t *out, int num_o
     HIP_TRY(hipEventRecord(b->ev_fetched, rs));
     HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_fetched, 0));
   }
+  int views = 0;
   for (int u = 0; u < num_out; ++u) {
     const int T = b->h_T[u];
     out[u].am = b->am;
     out[u].log_prob.ncol = T;
     out[u].log_prob.nrow = T > 0 ? N : 0;
     out[u].log_prob.data = T > 0 ? b->h_ll + (size_t)b->h_pad_base[u] * N : nullptr;
+    views += T > 0;
   }
+  SetArenaViews(b->h_ll, views);        // the views of an earlier fetch_all are void by contract
   if (sync) HIP_TRY(hipStreamSynchronize(b->stream));
   return 0;
 }
@@ -1373,6 +1483,30 @@ int pk_mi355_test_logf(const float *x, int n, float *out) {
   }
   hipFree(d_tab); hipFree(d_x); hipFree(d_y);
   if (e != hipSuccess) return Fail(PK_MI355_E_DEVICE, "test_logf: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int pk_mi355_test_srfft512(const float *frames, int num_frames, float *spectra) {
+  if (!frames || !spectra || num_frames < 0) return Fail(PK_MI355_E_INVALID, "bad argument");
+  int rc = UseDevice(g_device);
+  if (rc || num_frames == 0) return rc;
+  FrontendTables host;
+  if (BuildFrontendTables(&host)) return Fail(PK_MI355_E_INVALID, "front-end table construction failed");
+  const size_t bytes = sizeof(float) * (size_t)num_frames * kFftSize;
+  FrontendTables *d_tab = nullptr;
+  float *d_x = nullptr, *d_y = nullptr;
+  hipError_t e = hipMalloc(&d_tab, sizeof(host));
+  if (e == hipSuccess) e = hipMalloc(&d_x, bytes);
+  if (e == hipSuccess) e = hipMalloc(&d_y, bytes);
+  if (e == hipSuccess) e = hipMemcpy(d_tab, &host, sizeof(host), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_x, frames, bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    LaunchSrfft512Test(d_x, num_frames, d_tab, d_y, nullptr);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(spectra, d_y, bytes, hipMemcpyDeviceToHost);
+  hipFree(d_tab); hipFree(d_x); hipFree(d_y);
+  if (e != hipSuccess) return Fail(PK_MI355_E_DEVICE, "test_srfft512: %s", hipGetErrorString(e));
   return 0;
 }
 
@@ -1611,6 +1745,7 @@ int pk_mi355_process_acoustic(pk_mi355_am_t *am, const pk_vector_t *cmvn_global_
   out->am = am;
   out->log_prob.ncol = 0; out->log_prob.nrow = 0; out->log_prob.data = nullptr;
   if (raw_wave->dim == 0) return 0;                           // pocketkaldi.cc:180-184
+  std::lock_guard<std::mutex> lock(am->mu);
   const int64_t need = std::max<int64_t>(raw_wave->dim, 16000);
   if (!am->proc || need > am->proc_cap ||
       memcmp(am->proc_stats, cmvn_global_stats->data, sizeof(am->proc_stats)) != 0) {

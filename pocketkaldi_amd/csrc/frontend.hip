@@ -6,8 +6,8 @@
 // are bit-identical wherever IEEE arithmetic is; the file is compiled with
 // -ffp-contract=off so a*b+c is never fused where the reference's x86-64 build
 // does not fuse.  The only non-IEEE step is the final natural log (fbank.cc:245):
-// it is taken in fp64 and rounded once, which reproduces glibc's logf except for
-// rare 1-ULP cases.
+// it is the C library's own table-driven logf restated for the device (pk_logf.h,
+// checked against the system libm on every positive float), so it too is bit-identical.
 //
 // Execution shape: one 64-lane wavefront per frame, four independent waves per
 // workgroup; frame and constant tables live in LDS, the eight split-radix passes each
@@ -132,6 +132,72 @@ __device__ __forceinline__ void FftPass(f32x2 *z, int lane, const LdsTables &tab
   WaveSync();
 }
 
+__device__ __forceinline__ void CopyTablesToLds(LdsTables &tab, const FrontendTables *__restrict__ gtab) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < kLogfTableDoubles; i += nt) tab.logf_tab[i] = gtab->logf_tab[i];
+  for (int i = tid; i < kFrameLength; i += nt) tab.window[i] = gtab->window[i];
+  for (int i = tid; i < kTwFloats; i += nt) tab.tw[i] = gtab->tw[i];
+  for (int i = tid; i <= kFftCplx / 2; i += nt) { tab.post_re[i] = gtab->post_re[i]; tab.post_im[i] = gtab->post_im[i]; }
+  for (int i = tid; i < kMelPacked; i += nt) tab.mel_w[i] = gtab->mel_packed[i];
+  for (int i = tid; i < kNumBins; i += nt) {
+    tab.mel_off[i] = (short)gtab->mel_off[i];
+    tab.mel_len[i] = (short)gtab->mel_len[i];
+    tab.mel_base[i] = (short)gtab->mel_base[i];
+  }
+  for (int i = tid; i <= kLogCplx; i += nt) tab.tw_off[i] = (short)gtab->tw_off[i];
+  for (int i = tid; i <= kNumPasses; i += nt) tab.pass_start[i] = (short)gtab->pass_start[i];
+  for (int i = tid; i <= kMaxBlocks; i += nt) tab.blk_off[i] = (unsigned char)gtab->blk_off[i];
+  for (int i = tid; i < kFftCplx; i += nt) tab.bitrev[i] = (unsigned char)gtab->bitrev[i];
+}
+
+// srfft.cc:95-237: the 256-point complex split-radix DIF on the interleaved frame in LDS, one
+// wave, as eight passes over the block schedule; output in bit-reversed order.
+__device__ __forceinline__ void ComplexFft256(f32x2 *s_z, int lane, const LdsTables &tab) {
+  FftPass<8>(s_z, lane, tab);
+  FftPass<7>(s_z, lane, tab);
+  FftPass<6>(s_z, lane, tab);
+  FftPass<5>(s_z, lane, tab);
+  FftPass<4>(s_z, lane, tab);
+  FftPass<3>(s_z, lane, tab);
+  FftPass<2>(s_z, lane, tab);
+  {   // two-point blocks, srfft.cc:140-150
+    const int first = tab.pass_start[kNumPasses - 1];
+    const int nblk = tab.pass_start[kNumPasses] - first;
+    for (int b = lane; b < nblk; b += kWave) {
+      int off = tab.blk_off[first + b];
+      const f32x2 u0 = s_z[off], u1 = s_z[off + 1];
+      s_z[off] = f32x2{u0[0] + u1[0], u0[1] + u1[1]};
+      s_z[off + 1] = f32x2{u0[0] - u1[0], u0[1] - u1[1]};
+    }
+  }
+  WaveSync();
+}
+
+// The real-FFT post-pass for bin k (1..128) and its partner 256 - k: srfft.cc:389-436, with the
+// bit-reversed read of srfft.cc:239-265 folded in.  (a_re, a_im) is bin k, (o_re, o_im) bin 256 - k.
+struct RealBins { float a_re, a_im, o_re, o_im; };
+__device__ __forceinline__ RealBins RealPostPass(const f32x2 *s_z, const LdsTables &tab, int k) {
+  const int kd = kFftCplx - k;
+  const int jk = tab.bitrev[k], jd = tab.bitrev[kd];
+  const f32x2 zk = s_z[jk], zd = s_z[jd];
+  const float bk_re = zk[0], bk_im = zk[1];
+  const float bd_re = zd[0], bd_im = zd[1];
+  const float kre = tab.post_re[k], kim = tab.post_im[k];
+  const float ck_re = 0.5f * (bk_re + bd_re);
+  const float ck_im = 0.5f * (bk_im - bd_im);
+  const float dk_re = 0.5f * (bk_im + bd_im);
+  const float dk_im = -0.5f * (bk_re - bd_re);
+  RealBins rb;
+  rb.a_re = ck_re; rb.a_im = ck_im;
+  rb.a_re += kre * dk_re - kim * dk_im;
+  rb.a_im += kre * dk_im + kim * dk_re;
+  const float nk_re = -kre, ndk_im = -dk_im;
+  rb.o_re = ck_re; rb.o_im = -ck_im;
+  rb.o_re += nk_re * dk_re - kim * ndk_im;
+  rb.o_im += nk_re * ndk_im + kim * dk_re;
+  return rb;
+}
+
 constexpr int kFbankWaves = 4;
 
 // Each wave of a workgroup walks frames t = blockIdx.x * 4 + wave, + gridDim.x * 4, ...
@@ -144,23 +210,7 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
   __shared__ FrameLds frames[kFbankWaves];
 
   // ---- tables: global -> LDS, once per workgroup
-  {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int i = tid; i < kLogfTableDoubles; i += nt) tab.logf_tab[i] = gtab->logf_tab[i];
-    for (int i = tid; i < kFrameLength; i += nt) tab.window[i] = gtab->window[i];
-    for (int i = tid; i < kTwFloats; i += nt) tab.tw[i] = gtab->tw[i];
-    for (int i = tid; i <= kFftCplx / 2; i += nt) { tab.post_re[i] = gtab->post_re[i]; tab.post_im[i] = gtab->post_im[i]; }
-    for (int i = tid; i < kMelPacked; i += nt) tab.mel_w[i] = gtab->mel_packed[i];
-    for (int i = tid; i < kNumBins; i += nt) {
-      tab.mel_off[i] = (short)gtab->mel_off[i];
-      tab.mel_len[i] = (short)gtab->mel_len[i];
-      tab.mel_base[i] = (short)gtab->mel_base[i];
-    }
-    for (int i = tid; i <= kLogCplx; i += nt) tab.tw_off[i] = (short)gtab->tw_off[i];
-    for (int i = tid; i <= kNumPasses; i += nt) tab.pass_start[i] = (short)gtab->pass_start[i];
-    for (int i = tid; i <= kMaxBlocks; i += nt) tab.blk_off[i] = (unsigned char)gtab->blk_off[i];
-    for (int i = tid; i < kFftCplx; i += nt) tab.bitrev[i] = (unsigned char)gtab->bitrev[i];
-  }
+  CopyTablesToLds(tab, gtab);
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -248,24 +298,7 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
     WaveSync();
 
     // ---- srfft.cc:95-237 as passes over the block schedule
-    FftPass<8>(s_z, lane, tab);
-    FftPass<7>(s_z, lane, tab);
-    FftPass<6>(s_z, lane, tab);
-    FftPass<5>(s_z, lane, tab);
-    FftPass<4>(s_z, lane, tab);
-    FftPass<3>(s_z, lane, tab);
-    FftPass<2>(s_z, lane, tab);
-    {   // two-point blocks, srfft.cc:140-150
-      const int first = tab.pass_start[kNumPasses - 1];
-      const int nblk = tab.pass_start[kNumPasses] - first;
-      for (int b = lane; b < nblk; b += kWave) {
-        int off = tab.blk_off[first + b];
-        const f32x2 u0 = s_z[off], u1 = s_z[off + 1];
-        s_z[off] = f32x2{u0[0] + u1[0], u0[1] + u1[1]};
-        s_z[off + 1] = f32x2{u0[0] - u1[0], u0[1] - u1[1]};
-      }
-    }
-    WaveSync();
+    ComplexFft256(s_z, lane, tab);
 
     // ---- bit-reversed read (srfft.cc:239-265), real post-pass (srfft.cc:389-436)
     // and power spectrum (fbank.cc:193-211) fused: bin k and its partner 256-k.
@@ -273,26 +306,9 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
     for (int r = 0; r < 2; ++r) {
       const int k = 1 + lane + kWave * r;            // 1..128
       const int kd = kFftCplx - k;
-      const int jk = tab.bitrev[k], jd = tab.bitrev[kd];
-      const f32x2 zk = s_z[jk], zd = s_z[jd];
-      const float bk_re = zk[0], bk_im = zk[1];
-      const float bd_re = zd[0], bd_im = zd[1];
-      const float kre = tab.post_re[k], kim = tab.post_im[k];
-      const float ck_re = 0.5f * (bk_re + bd_re);
-      const float ck_im = 0.5f * (bk_im - bd_im);
-      const float dk_re = 0.5f * (bk_im + bd_im);
-      const float dk_im = -0.5f * (bk_re - bd_re);
-      float a_re = ck_re, a_im = ck_im;
-      a_re += kre * dk_re - kim * dk_im;
-      a_im += kre * dk_im + kim * dk_re;
-      s_pow[k] = a_re * a_re + a_im * a_im;
-      if (kd != k) {
-        const float nk_re = -kre, ndk_im = -dk_im;
-        float o_re = ck_re, o_im = -ck_im;
-        o_re += nk_re * dk_re - kim * ndk_im;
-        o_im += nk_re * ndk_im + kim * dk_re;
-        s_pow[kd] = o_re * o_re + o_im * o_im;
-      }
+      const RealBins rb = RealPostPass(s_z, tab, k);
+      s_pow[k] = rb.a_re * rb.a_re + rb.a_im * rb.a_im;
+      if (kd != k) s_pow[kd] = rb.o_re * rb.o_re + rb.o_im * rb.o_im;
     }
     if (lane == 0) {                                 // srfft.cc:444-447, fbank.cc:201-210
       const f32x2 z00 = s_z[0];
@@ -476,6 +492,46 @@ __global__ void LogfTestKernel(const float *__restrict__ x, int n, const Fronten
                                float *__restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = LogfRestated(x[i], gtab->logf_tab);
+}
+
+// Parity-test hook: pk_srfft_compute (srfft.cc:371-461) alone -- the FFT passes and the real
+// post-pass of FbankKernel on caller-supplied 512-sample frames, packed output
+// [Re0 + Im0, Re0 - Im0, Re1, Im1, ..., Re255, Im255] (srfft.cc:444-447).  One wave per frame.
+__global__ __launch_bounds__(kWave) void Srfft512TestKernel(const float *__restrict__ frames, int n,
+                                                            const FrontendTables *__restrict__ gtab,
+                                                            float *__restrict__ out) {
+  __shared__ LdsTables tab;
+  __shared__ f32x2 s_z[kFftCplx];
+  CopyTablesToLds(tab, gtab);
+  __syncthreads();
+  const int lane = threadIdx.x;
+  for (int f = blockIdx.x; f < n; f += gridDim.x) {
+    const float *x = frames + (int64_t)f * kFftSize;
+    float *y = out + (int64_t)f * kFftSize;
+    for (int i = lane; i < kFftCplx; i += kWave) s_z[i] = f32x2{x[2 * i], x[2 * i + 1]};
+    WaveSync();
+    ComplexFft256(s_z, lane, tab);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int k = 1 + lane + kWave * r;
+      const int kd = kFftCplx - k;
+      const RealBins rb = RealPostPass(s_z, tab, k);
+      y[2 * k] = rb.a_re;
+      y[2 * k + 1] = rb.a_im;
+      if (kd != k) { y[2 * kd] = rb.o_re; y[2 * kd + 1] = rb.o_im; }
+    }
+    if (lane == 0) {
+      const f32x2 z00 = s_z[0];
+      y[0] = z00[0] + z00[1];
+      y[1] = z00[0] - z00[1];
+    }
+    WaveSync();
+  }
+}
+
+void LaunchSrfft512Test(const float *frames, int n, const FrontendTables *d_tables, float *out, hipStream_t stream) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(Srfft512TestKernel, dim3(n < 1024 ? n : 1024), dim3(kWave), 0, stream, frames, n, d_tables, out);
 }
 
 void LaunchLogfTest(const float *x, int n, const FrontendTables *d_tables, float *out, hipStream_t stream) {

@@ -27,6 +27,8 @@ void LaunchFbank(const float *wave_f32, const int16_t *wave_i16, const UttLayout
 
 // parity-test hook: the kernel's logf (pk_logf.h) on n device floats
 void LaunchLogfTest(const float *x, int n, const FrontendTables *d_tables, float *out, hipStream_t stream);
+// parity-test hook: the kernel's 512-point real FFT (srfft.cc:371-461) on n device frames of 512 floats
+void LaunchSrfft512Test(const float *frames, int n, const FrontendTables *d_tables, float *out, hipStream_t stream);
 
 // cmvn.cc:103-115 for a batch: raw [sum T][40] -> feature-major, edge-padded
 // Yt[40][ldy]: utterance u occupies columns pad_base[u] .. pad_base[u]+T+left+right-1,

@@ -36,7 +36,8 @@ __global__ void ReluKernel(float *__restrict__ x, int64_t n) {
 }
 
 // One lane per frame, features walked in ascending order: the float sum of
-// squares is the reference's sequential VecVec (vector.cc:252-262).
+// squares is the reference's sequential VecVec (vector.cc:252-262).  Feature-major panels
+// (stride_f == 1): the 64 lanes of a wave read 64 consecutive frames of one feature -- coalesced.
 __global__ void NormalizeKernel(float *__restrict__ x, int frames, int dim, int64_t stride_f,
                                 int64_t stride_d) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,6 +52,47 @@ __global__ void NormalizeKernel(float *__restrict__ x, int frames, int dim, int6
   const double squared_sum = ss;
   const float scale = static_cast<float>(sqrt(D / squared_sum));     // nnet.cc:71-72
   for (int d = 0; d < dim; ++d) row[(int64_t)d * stride_d] *= scale;
+}
+
+// The same for frame-major rows (stride_d == 1), where a lane per frame would walk its own row:
+// a workgroup owns 64 frames, 64 x 64 tiles of them are loaded with coalesced 256-byte row pieces
+// and transposed through LDS, and one wave -- lane = frame -- adds the squares tile after tile in
+// feature order (the order is the reference's; only the loads are reshaped).  The scaling pass
+// is elementwise and runs coalesced on all four waves.
+__global__ __launch_bounds__(256) void NormalizeRowsKernel(float *__restrict__ x, int frames, int dim, int64_t ld) {
+  __shared__ float tile[64][65];
+  __shared__ float s_scale[64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int f0 = blockIdx.x * 64;
+  float ss = 0.0f;
+  for (int d0 = 0; d0 < dim; d0 += 64) {
+    for (int r = wv; r < 64; r += 4) {
+      const int f = f0 + r, d = d0 + lane;
+      tile[r][lane] = (f < frames && d < dim) ? x[(int64_t)f * ld + d] : 0.0f;   // + 0 * 0 leaves the sum as it is
+    }
+    __syncthreads();
+    if (wv == 0) {
+      const int nd = dim - d0 < 64 ? dim - d0 : 64;
+      for (int c = 0; c < nd; ++c) {
+        const float v = tile[lane][c];
+        ss += v * v;
+      }
+    }
+    __syncthreads();
+  }
+  if (wv == 0) {
+    const float D = static_cast<float>(dim);
+    const double squared_sum = ss;
+    s_scale[lane] = static_cast<float>(sqrt(D / squared_sum));        // nnet.cc:71-72
+  }
+  __syncthreads();
+  for (int r = wv; r < 64; r += 4) {
+    const int f = f0 + r;
+    if (f >= frames) break;
+    const float sc = s_scale[r];
+    float *row = x + (int64_t)f * ld;
+    for (int d = lane; d < dim; d += 64) row[d] *= sc;
+  }
 }
 
 // 32 x 32 tile transpose through LDS (+1 padding), 256 threads.
@@ -191,6 +233,52 @@ __global__ __launch_bounds__(kTailThreads) void TailKernel(const float *__restri
   }
 }
 
+// Rows wider than the register cache of TailKernel (n > 8192): the same arithmetic in three
+// passes over the row (max, sum of exponentials, output); the second and third pass re-read the
+// row from L2.  Outside the BASELINE models (3 000 / 8 000 pdfs); kept simple.
+template <int MODE>
+__global__ __launch_bounds__(kTailThreads) void TailWideKernel(const float *__restrict__ in, int64_t ld_in,
+                                                               int rows, int n,
+                                                               const float *__restrict__ log_prior, float scale,
+                                                               float *__restrict__ out, int64_t ld_out) {
+  __shared__ float red[2][kTailThreads / 64];
+  const int tid = threadIdx.x;
+  const float kLogFloor = -46.051701859880914f;  // logf(1e-20f), am.cc:109-110
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const float *x = in + (int64_t)row * ld_in;
+    float *y = out + (int64_t)row * ld_out;
+    float m = -INFINITY, lse = 0.0f, inv = 0.0f;
+    if (MODE != kTailLoglik) {
+      for (int c = tid; c < n; c += kTailThreads) m = fmaxf(m, x[c]);
+      m = WaveMax(m);
+      if ((tid & 63) == 0) red[0][tid >> 6] = m;
+      __syncthreads();
+      m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+      float s = 0.0f;
+      for (int c = tid; c < n; c += kTailThreads) s += expf(x[c] - m);
+      s = WaveSum(s);
+      if ((tid & 63) == 0) red[1][tid >> 6] = s;
+      __syncthreads();
+      s = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+      lse = m + logf(s);
+      inv = 1.0f / s;
+    }
+    for (int c = tid; c < n; c += kTailThreads) {
+      float t = x[c];
+      if (MODE == kTailSoftmaxProb) {
+        t = expf(t - m) * inv;
+      } else {
+        if (MODE == kTailSoftmaxLoglik) t = t - lse;
+        else t = LogfRestated(t < 1.0e-20f ? 1.0e-20f : t, kLogfTab);
+        if (t < kLogFloor) t = kLogFloor;
+        t = (t + -1.0f * log_prior[c]) * scale;
+      }
+      y[c] = t;
+    }
+    __syncthreads();          // red[] is reused by the next row
+  }
+}
+
 // decodable.cc:24-31 for many (frame, transition-id) pairs at once, device side:
 // out[i] = ll[frame[i]][tid2pdf[tid[i]]]
 __global__ void GatherKernel(const float *__restrict__ ll, int64_t ld, const int32_t *__restrict__ tid2pdf,
@@ -225,8 +313,11 @@ void LaunchRelu(float *x, int64_t n, hipStream_t stream) {
 void LaunchNormalize(float *x, int frames, int dim, int64_t stride_f, int64_t stride_d,
                      hipStream_t stream) {
   if (frames <= 0) return;
-  hipLaunchKernelGGL(NormalizeKernel, dim3((frames + 63) / 64), dim3(64), 0, stream, x, frames,
-                     dim, stride_f, stride_d);
+  if (stride_d == 1 && stride_f != 1)
+    hipLaunchKernelGGL(NormalizeRowsKernel, dim3((frames + 63) / 64), dim3(256), 0, stream, x, frames, dim, stride_f);
+  else
+    hipLaunchKernelGGL(NormalizeKernel, dim3((frames + 63) / 64), dim3(64), 0, stream, x, frames,
+                       dim, stride_f, stride_d);
 }
 
 void LaunchTransposeToRows(const float *in, int64_t ld_in, int dim, int frames, float *out,
@@ -356,8 +447,10 @@ static void LaunchTailMode(const float *in, int64_t ld_in, int rows, int n, cons
     hipLaunchKernelGGL((TailKernel<MODE, 1>), grid, block, 0, stream, in, ld_in, rows, n, log_prior, scale, out, ld_out);
   else if (n4 <= 3 * kTailThreads)
     hipLaunchKernelGGL((TailKernel<MODE, 3>), grid, block, 0, stream, in, ld_in, rows, n, log_prior, scale, out, ld_out);
-  else
+  else if (n4 <= kTailCacheMax * kTailThreads)
     hipLaunchKernelGGL((TailKernel<MODE, kTailCacheMax>), grid, block, 0, stream, in, ld_in, rows, n, log_prior, scale, out, ld_out);
+  else
+    hipLaunchKernelGGL((TailWideKernel<MODE>), grid, block, 0, stream, in, ld_in, rows, n, log_prior, scale, out, ld_out);
 }
 
 void LaunchTail(int mode, bool reference_exact, const float *in, int64_t ld_in, int rows, int n,

@@ -92,3 +92,15 @@ class DeviceBytes:
 
 def alias_device_bytes(ptr, nbytes, device):
     return torch.as_tensor(DeviceBytes(ptr, nbytes), device=device)
+
+
+def broadcast_model(am, device, src=0):
+    """Replicate rank `src`'s weights into this rank's model, in place: the model's packed device
+    blob is aliased as a torch tensor (zero-copy) and broadcast -- the ONE collective of the path
+    (RCCL over xGMI with backend "nccl"; staged through the host under the gloo rehearsal backend).
+    The C/C++ form of the same step is pk_mi355_am_broadcast (include/pk_mi355.h)."""
+    if not dist.is_initialized():
+        return
+    ptr, nbytes = am.blob()
+    broadcast_blob(alias_device_bytes(ptr, nbytes, device), src=src)
+    torch.cuda.synchronize(device)

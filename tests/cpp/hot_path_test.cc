@@ -1,7 +1,7 @@
 // hot_path_test.cc -- the reference's own test programs for this path (test/fbank_test.cc,
 // test/cmvn_test.cc, test/nnet_test.cc), re-expressed against include/pocketkaldi_amd.hpp:
 // a C++ caller written the way the reference's callers are, linked to libpk_mi355.so.
-// Built and run by tests/test_gpu_cpp.py (needs a GPU); `--link-only` exits before any compute.
+// Built and run by tests/test_cpp_host.py (needs a GPU); `--link-only` exits before any compute.
 #include <assert.h>
 #include <math.h>
 #include <stdio.h>

@@ -13,7 +13,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_line_has_the_contract_keys():
     out = subprocess.check_output(
         [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8",
-         "--seconds", "2", "--cpu-utts", "2", "--no-other-configs"], text=True, cwd=REPO)
+         "--seconds", "2", "--cpu-seconds", "1", "--no-other-configs"], text=True, cwd=REPO)
     lines = [l for l in out.splitlines() if l.strip()]
     assert len(lines) == 1, "exactly one line on stdout"
     d = json.loads(lines[0])
@@ -25,12 +25,18 @@ def test_bench_line_has_the_contract_keys():
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" in d["config"]
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"):
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+    # SURVEY section 8d's three end-points travel in the same line; `value` stays device-complete
+    e = d["endpoints"]
+    assert e["device_complete"]["value"] == d["value"]
+    for k in ("from_pinned_host", "host_complete"):
+        assert e[k]["unit"] == "frames/s" and 0 < e[k]["value"] <= 1.05 * d["value"]
+    assert "time-capped" in c["sample"] and "time-capped" in d["cpu_baseline_all_cores"]["sample"]
     # value = frames of all steps / wall time
     assert abs(d["value"] - d["config"]["frames_per_gpu_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6

@@ -707,3 +707,131 @@ def test_fuzz_ragged_batches_every_stage(seed, monkeypatch):
                 assert bits_equal(got, ll)
             else:
                 assert_loglik_close(got, ll)
+
+
+# ------------------------------------------------------------------ round-2 additions
+
+def test_device_fft_bit_exact_vs_committed_real_reference_output():
+    """The kernel's 512-point real FFT alone (pk_mi355_test_srfft512: the FFT passes + real
+    post-pass FbankKernel runs) on tests/golden/ref_srfft512.npz["frames"] == ["spectra"], which
+    are outputs of the REAL pk_srfft_compute (srfft.cc:371-461) built from the reference's own
+    file in the build container (tests/golden/make_ref_fixtures.py).  A direct pin, bitwise."""
+    z = np.load(os.path.join(G, "ref_srfft512.npz"))
+    got = pk.device_srfft512(z["frames"])
+    assert bits_equal(got, z["spectra"])
+    # and against the oracle's restatement on more frames (incl. magnitudes of real PCM windows)
+    rng = np.random.default_rng(21)
+    frames = (rng.standard_normal((300, 512)) * rng.choice([1e-3, 1.0, 3e3, 3e4], size=(300, 1))).astype(np.float32)
+    fft = O.Srfft(512)
+    assert bits_equal(pk.device_srfft512(frames), np.stack([fft.forward(f) for f in frames]))
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_outputs_wider_than_the_tail_register_cache(prec):
+    """More than 8192 pdfs: the three-pass tail (tail.hip TailWideKernel) takes over -- every column
+    takes part in the softmax and is written (f16x3 used to drop columns >= 8192)."""
+    N, D = 8200, 40
+    rng = np.random.default_rng(8200)
+    W = (rng.standard_normal((N, D)) * 0.3).astype(np.float32)
+    b = (rng.standard_normal(N) * 0.5).astype(np.float32)
+    layers = [("linear", W, b), ("softmax",)]
+    prior = rng.uniform(0.5, 1.5, N)
+    prior = (prior / prior.sum()).astype(np.float32)
+    feats = rng.standard_normal((37, D)).astype(np.float32)
+    am = pk.AcousticModel(layers, prior, 0, 0, precision=prec)
+    lp = pk.Decodable(am, 0.1, feats).log_prob()
+    ref = O.Nnet(layers).am_compute(feats, prior, 0, 0, 0.1)
+    assert_loglik_close(lp, ref)
+    p = am.propagate(feats)                       # probabilities, the kTailSoftmaxProb form
+    assert np.allclose(p.sum(axis=1), 1.0, atol=1e-5) and np.all(p[:, 8192:] > 0)
+    # no softmax layer: the plain floor / log / prior tail on a wide output
+    layers2 = [("linear", np.abs(W), np.abs(b)), ("relu",)]
+    lp2 = pk.Decodable(pk.AcousticModel(layers2, prior, 0, 0, precision=prec), 1.0, np.abs(feats)).log_prob()
+    assert_loglik_close(lp2, O.Nnet(layers2).am_compute(np.abs(feats), prior, 0, 0, 1.0))
+
+
+def test_f16x3_spliced_entry_needs_feature_dim_multiple_of_8():
+    """the interleaved (hi, lo) frame row exists only for feat_dim % 8 == 0; other widths
+    must fail loudly in pk_decodable_init instead of writing out of bounds."""
+    rng = np.random.default_rng(3)
+    W = rng.standard_normal((16, 60)).astype(np.float32)
+    am = pk.AcousticModel([("linear", W, np.zeros(16, np.float32)), ("softmax",)],
+                          np.full(16, 1 / 16, np.float32), 1, 1, precision="f16x3")     # feat_dim = 20
+    with pytest.raises(pk.PkError, match="multiple of 8"):
+        pk.Decodable(am, 0.1, rng.standard_normal((9, 20)).astype(np.float32))
+    # the plain (non-spliced) entry pads rows itself and stays usable; f32 takes any width
+    assert am.propagate(rng.standard_normal((9, 60)).astype(np.float32)).shape == (9, 16)
+    am32 = pk.AcousticModel([("linear", W, np.zeros(16, np.float32)), ("softmax",)],
+                            np.full(16, 1 / 16, np.float32), 1, 1)
+    assert pk.Decodable(am32, 0.1, rng.standard_normal((9, 20)).astype(np.float32)).log_prob().shape == (9, 16)
+
+
+def test_view_destroyed_after_its_batch_is_safe():
+    """VERDICT r1 #10 (gpurun_out/seg.log): the reference's caller destroys its decodable
+    unconditionally at the end (pocketkaldi.cc:247), possibly after pk_mi355_batch_destroy.  The
+    arena now lives until the batch AND the views of its last fetch_all are gone: reading a view
+    after the batch is destroyed is still valid, destroying it frees the arena, once."""
+    import ctypes as C
+    L_ = pk.lib()
+    layers, prior, L, R = synth.model("tiny")
+    am = pk.AcousticModel(layers, prior, L, R)
+    waves = [synth.utterance(50 + u, 0.6) for u in range(3)] + [np.zeros(10, np.float32)]   # last: T = 0
+    bs = pk.BatchScorer(am, synth.global_cmvn_stats(), len(waves), sum(len(w) for w in waves))
+    bs.set_waves(waves)
+    bs.score(0.1)
+    want = [bs.fetch(u).log_prob() for u in range(len(waves))]
+    arr = (pk.pk_decodable_t * len(waves))()
+    assert L_.pk_mi355_batch_fetch_all(bs._h, arr, len(waves), 1) == 0
+    L_.pk_mi355_batch_destroy(bs._h)            # the batch goes first ...
+    bs._h = None
+    for u in range(len(waves)):                 # ... the views are still readable ...
+        lp = arr[u].log_prob
+        if lp.ncol:
+            got = np.ctypeslib.as_array(lp.data, shape=(lp.ncol, lp.nrow)).copy()
+            assert bits_equal(got, want[u])
+            assert L_.pk_decodable_islastframe(C.byref(arr[u]), lp.ncol - 1)
+    for u in range(len(waves)):                 # ... and destroying them is safe (the last one releases the arena)
+        L_.pk_decodable_destroy(C.byref(arr[u]))
+        assert not arr[u].log_prob.data and arr[u].log_prob.ncol == 0
+    # the heap is intact: malloc-backed decodables still work
+    d = pk.Decodable(am, 0.1, np.zeros((5, 40), np.float32))
+    assert d.log_prob().shape == (5, 50)
+    d.destroy()
+    # Python mirror: closing the scorer while views are alive, views die later
+    bs2 = pk.BatchScorer(am, synth.global_cmvn_stats(), 3, sum(len(w) for w in waves[:3]))
+    bs2.set_waves(waves[:3])
+    bs2.score(0.1)
+    views = bs2.fetch_all()
+    bs2.close()
+    assert bits_equal(views[1].log_prob(), want[1])
+    del views
+
+
+def test_one_model_shared_by_host_threads():
+    """the reference's pk_decodable_init is re-entrant for a shared model (nnet.cc:149-163
+    allocates per call); ours serialises on a per-model lock -- concurrent callers get their own,
+    correct results."""
+    import threading
+    layers, prior, L, R, tid2pdf = tiny_model()
+    am = pk.AcousticModel(layers, prior, L, R, tid2pdf)
+    rng = np.random.default_rng(99)
+    feats = [rng.standard_normal((40 + 37 * i, 40)).astype(np.float32) for i in range(6)]
+    want = [pk.Decodable(am, 0.1, f).log_prob() for f in feats]
+    got = [None] * len(feats)
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                got[i] = pk.Decodable(am, 0.1, feats[i]).log_prob()
+        except Exception as e:      # noqa
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(feats))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs
+    for a, b in zip(got, want):
+        assert bits_equal(a, b)
