@@ -1141,7 +1141,8 @@ struct pk_mi355_batch {
   int64_t *d_wave_off = nullptr, *d_raw_base = nullptr, *d_pad_base = nullptr;
   int32_t *d_T = nullptr;
   // stages
-  float *d_raw = nullptr;   // [max_frames][40]
+  float *d_raw_alloc = nullptr;
+  float *d_raw = nullptr;   // [max_frames][40], kCmvnRawLead floats into d_raw_alloc
   float *d_yt = nullptr;    // [feat_dim][ldy]
   _Float16 *d_y2 = nullptr;   // f16x3: interleaved (hi, lo) rows [ldy][2 feat_dim]
   int64_t ldy = 0;
@@ -1246,7 +1247,10 @@ pk_mi355_batch_t *pk_mi355_batch_create(pk_mi355_am_t *am, const float *global_s
   chk(hipMalloc(&b->d_raw_base, sizeof(int64_t) * max_utts));
   chk(hipMalloc(&b->d_pad_base, sizeof(int64_t) * max_utts));
   chk(hipMalloc(&b->d_T, sizeof(int32_t) * max_utts));
-  chk(hipMalloc(&b->d_raw, sizeof(float) * b->max_frames * kNumBins));
+  const size_t raw_floats = (size_t)b->max_frames * kNumBins + kCmvnRawLead + kCmvnRawSlack;
+  chk(hipMalloc(&b->d_raw_alloc, sizeof(float) * raw_floats));
+  if (ok) chk(hipMemset(b->d_raw_alloc, 0, sizeof(float) * raw_floats));
+  if (ok) b->d_raw = b->d_raw_alloc + kCmvnRawLead;
   chk(hipMalloc(&b->d_yt, sizeof(float) * b->ldy * kNumBins));
   if (ok) chk(hipMemset(b->d_yt, 0, sizeof(float) * b->ldy * kNumBins));
   if (am->precision == PK_MI355_PRECISION_F16X3) {
@@ -1279,7 +1283,7 @@ void pk_mi355_batch_destroy(pk_mi355_batch_t *b) {
   hipFree(b->d_tables); hipFree(b->d_global); hipFree(b->d_cmvn_tab);
   hipFree(b->d_wave); hipFree(b->d_wave_i16);
   hipFree(b->d_wave_off); hipFree(b->d_raw_base); hipFree(b->d_pad_base); hipFree(b->d_T);
-  hipFree(b->d_raw); hipFree(b->d_yt); hipFree(b->d_y2); hipFree(b->d_ll);
+  hipFree(b->d_raw_alloc); hipFree(b->d_yt); hipFree(b->d_y2); hipFree(b->d_ll);
   if (b->h_ll) RetireArena(b->h_ll);     // released now, or by the last outstanding view
   if (b->ev_scored) hipEventDestroy(b->ev_scored);
   if (b->ev_fetched) hipEventDestroy(b->ev_fetched);
@@ -1661,7 +1665,11 @@ int pk_mi355_cmvn_apply(const pk_vector_t *global_stats, const pk_matrix_t *raw,
   std::vector<float> tmp((size_t)kNumBins * T);
   hipError_t e = hipSuccess;
   auto step = [&](hipError_t x) { if (e == hipSuccess) e = x; };
-  step(hipMalloc(&d_raw, sizeof(float) * (size_t)T * kNumBins));
+  float *d_raw_alloc = nullptr;
+  const size_t raw_floats = (size_t)T * kNumBins + kCmvnRawLead + kCmvnRawSlack;
+  step(hipMalloc(&d_raw_alloc, sizeof(float) * raw_floats));
+  if (e == hipSuccess) step(hipMemset(d_raw_alloc, 0, sizeof(float) * raw_floats));
+  d_raw = d_raw_alloc ? d_raw_alloc + kCmvnRawLead : nullptr;
   step(hipMalloc(&d_g, sizeof(float) * (kNumBins + 1)));
   step(hipMalloc(&d_ctab, sizeof(CmvnTables)));
   step(hipMalloc(&d_yt, sizeof(float) * ld * kNumBins));
@@ -1686,7 +1694,7 @@ int pk_mi355_cmvn_apply(const pk_vector_t *global_stats, const pk_matrix_t *raw,
   else
     for (int t = 0; t < T; ++t)
       for (int d = 0; d < kNumBins; ++d) out->data[(size_t)t * kNumBins + d] = tmp[(size_t)d * T + t];
-  hipFree(d_raw); hipFree(d_g); hipFree(d_ctab); hipFree(d_yt); hipFree(d_i64); hipFree(d_T);
+  hipFree(d_raw_alloc); hipFree(d_g); hipFree(d_ctab); hipFree(d_yt); hipFree(d_i64); hipFree(d_T);
   return ret;
 }
 

@@ -17,6 +17,7 @@
 
 #include <type_traits>
 
+#include "pk_dma.h"
 #include "pk_kernels.h"
 #include "pk_logf.h"
 
@@ -336,27 +337,53 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
 
 // One workgroup of four wavefronts per utterance.  The running window sum is rounded to float
 // every frame (cmvn.cc:66-70), so ONE wavefront walks the frames in order, one lane per
-// feature, and does nothing but that chain -- widen, one fp64 add (two once the window
-// slides), narrow -- leaving S_t in LDS.  Everything else is parallel over frames and belongs
-// to the other waves: one moves frames HBM -> LDS by LDS-DMA a tile (64 frames, 10 KiB) ahead,
-// two turn (x_t, S_t) of the previous tile into y_t (lane = frame) and store rows of 64
-// consecutive frames (256 bytes) into the feature-major operand of the first affine layer.
+// feature, and does nothing but that chain -- one f32 add while the window fills (for floats,
+// float(double(s) + double(x)) IS s + x: the double sum is exact or differs from it by less than
+// a quarter of a float ulp), widen / two fp64 adds / narrow once it slides -- leaving S_t in LDS.
+// Everything else is parallel over frames and belongs to the other waves: one moves frames
+// HBM -> LDS by LDS-DMA, kCmvnAhead tiles (64 frames, 10 KiB each) ahead of the chain with a
+// counted wait, so that the chain never waits for memory (with one tile of lead the kernel ran at
+// one DMA round trip per tile: 2.9 us per 64 frames); two turn (x_t, S_t) of the previous tile
+// into y_t (lane = frame, 16-byte LDS reads of four features) and store rows of 64 consecutive
+// frames (256 bytes) into the feature-major operand of the first affine layer.
 // The window count is min(t + 1, 600), so the smoothing weight and the 1/count scale come
 // from the host-built CmvnTables.  One raw s_barrier per tile.
 constexpr int kCmvnTile = 64;                                   // frames per tile
 constexpr int kCmvnTileFloats = kCmvnTile * kNumBins;           // 2560 floats = 10 KiB
 constexpr int kCmvnWaves = 4;                                   // chain, two writers, loader
+constexpr int kCmvnAhead = 3;                                   // tiles requested beyond the chain's
+constexpr int kCmvnInSlots = kCmvnAhead + 2;                    // writers' tile, chain's tile, kCmvnAhead ahead
+constexpr int kCmvnOldSlots = kCmvnAhead + 1;
+constexpr int kCmvnPieces = kCmvnTileFloats / 256;              // 1 KiB DMA instructions per tile: 10
+static_assert(kCmvnRawSlack >= kCmvnTileFloats, "the loader reads whole tiles");
+static_assert(kCmvnRawLead >= kCmvnWindow * kNumBins - (kCmvnWindow / kCmvnTile) * kCmvnTileFloats,
+              "the first sliding tile starts this far before frame 0");
+
+// s_waitcnt vmcnt(n) for the run-time multiples of kCmvnPieces the loader needs (the count is an
+// immediate; the loader wave branches on a wave-uniform value)
+__device__ __forceinline__ void CmvnWaitOutstanding(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+  }
+}
+static_assert(kCmvnPieces == 10 && kCmvnAhead <= 3, "CmvnWaitOutstanding covers at most 2 tiles x 20 pieces");
 
 __global__ __launch_bounds__(kWave * kCmvnWaves) void CmvnKernel(
     const float *__restrict__ raw, UttLayout utts, const float *__restrict__ g,
     const CmvnTables *__restrict__ tab, int left, int right, float *__restrict__ yt, int64_t ldy) {
   // ONE LDS array, carved by hand: with several __shared__ objects hipcc waits for the
   // in-flight LDS-DMA before every LDS read
-  __shared__ __attribute__((aligned(16))) float lds[7 * kCmvnTileFloats + 2 * kCmvnWindow];
-  float *s_in = lds;                                  // [3][tile]: x[t][d]  (loading / chain / writers)
-  float *s_old = lds + 3 * kCmvnTileFloats;           // [2][tile]: x[t - 600][d]
-  float *s_sum = lds + 5 * kCmvnTileFloats;           // [2][tile]: S_t[d], the window sums after frame t
-  float *s_alpha = lds + 7 * kCmvnTileFloats, *s_nscale = s_alpha + kCmvnWindow;
+  constexpr int kLdsFloats = (kCmvnInSlots + kCmvnOldSlots + 2) * kCmvnTileFloats + 2 * kCmvnWindow + 64;
+  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+  float *s_in = lds;                                            // [kCmvnInSlots][tile]: x[t][d]
+  float *s_old = s_in + kCmvnInSlots * kCmvnTileFloats;         // [kCmvnOldSlots][tile]: x[t - 600][d]
+  float *s_sum = s_old + kCmvnOldSlots * kCmvnTileFloats;       // [2][tile]: S_t[d], the window sums after frame t
+  float *s_alpha = s_sum + 2 * kCmvnTileFloats, *s_nscale = s_alpha + kCmvnWindow;
+  float *s_g = s_nscale + kCmvnWindow;                          // the 40 global sums
 
   const int lane = threadIdx.x & 63;
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 chain, 1-2 writers, 3 loader
@@ -365,28 +392,30 @@ __global__ __launch_bounds__(kWave * kCmvnWaves) void CmvnKernel(
   if (T <= 0) return;
   const float *x0 = raw + utts.raw_base[utt] * kNumBins;
   float *y0 = yt + utts.pad_base[utt];
-  for (int i = threadIdx.x; i < kCmvnWindow; i += kWave * kCmvnWaves) { s_alpha[i] = tab->alpha[i]; s_nscale[i] = tab->neg_scale[i]; }
 
   typedef const __attribute__((address_space(1))) void *GlobalPtr;
   typedef __attribute__((address_space(3))) void *LdsPtr;
   const int ntiles = (T + kCmvnTile - 1) / kCmvnTile;
-  // tile i of the utterance -> s_in[i % 3], the frames leaving the window -> s_old[i % 2].
-  // 10 x 1 KiB pieces each; source clamped to the utterance (clamped values are unused).
+  auto slides = [](int i) { return (i + 1) * kCmvnTile > kCmvnWindow; };   // some frame of tile i has t >= 600
+  auto pieces = [&](int i) { return i < ntiles ? (slides(i) ? 2 * kCmvnPieces : kCmvnPieces) : 0; };
+  // tile i of the utterance -> s_in[i % kCmvnInSlots], the frames leaving the window ->
+  // s_old[i % kCmvnOldSlots].  Scalar-base LDS-DMA (pk_dma.h): a piece is 1 KiB of consecutive
+  // floats, so the source is a wave-uniform base + lane * 16 bytes and the loader issues no
+  // vector arithmetic at all.  The last tile reads past the utterance (into the next utterance,
+  // or into the kCmvnRawSlack floats every raw buffer carries behind its last frame) and the
+  // first sliding tile starts 24 frames before it (the previous utterance, or the kCmvnRawLead
+  // floats in front of the first frame): values nobody uses, from memory that exists.
+  const uint32_t lane_off = (uint32_t)lane * 16u;
   auto fetch = [&](int i) {
-    const int64_t total = (int64_t)T * kNumBins;
-    float *din = s_in + (i % 3) * kCmvnTileFloats, *dold = s_old + (i & 1) * kCmvnTileFloats;
-    const bool slides = (i + 1) * kCmvnTile > kCmvnWindow;     // some frame of the tile has t >= 600
+    float *din = s_in + (i % kCmvnInSlots) * kCmvnTileFloats, *dold = s_old + (i % kCmvnOldSlots) * kCmvnTileFloats;
+    const bool sl = slides(i);
+    const int e0 = i * kCmvnTileFloats;                      // float index of the tile in the utterance
 #pragma unroll
-    for (int p = 0; p < kCmvnTileFloats / 256; ++p) {
-      int64_t e = (int64_t)i * kCmvnTileFloats + p * 256 + lane * 4;          // float index in the utterance
-      int64_t ec = e + 4 <= total ? e : total - 4;
-      if (ec < 0) ec = 0;
-      __builtin_amdgcn_global_load_lds((GlobalPtr)(x0 + ec), (LdsPtr)(din + p * 256), 16, 0, 0);
-      if (slides) {
-        int64_t o = e - (int64_t)kCmvnWindow * kNumBins;
-        int64_t oc = o < 0 ? 0 : (o + 4 <= total ? o : total - 4);
-        if (oc < 0) oc = 0;
-        __builtin_amdgcn_global_load_lds((GlobalPtr)(x0 + oc), (LdsPtr)(dold + p * 256), 16, 0, 0);
+    for (int p = 0; p < kCmvnPieces; ++p) {
+      DmaScalarBase(din + p * 256, reinterpret_cast<const char *>(x0 + e0 + p * 256), lane_off);
+      if (sl) {
+        const int o = e0 + p * 256 - kCmvnWindow * kNumBins;      // >= -kCmvnRawLead
+        DmaScalarBase(dold + p * 256, reinterpret_cast<const char *>(x0 + o), lane_off);
       }
     }
   };
@@ -396,22 +425,40 @@ __global__ __launch_bounds__(kWave * kCmvnWaves) void CmvnKernel(
   };
 
   if (role == 3) {
-    fetch(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < kCmvnAhead; ++i)
+      if (i < ntiles) fetch(i);
+    int later = 0;
+#pragma unroll
+    for (int i = 1; i < kCmvnAhead; ++i) later += pieces(i);
+    CmvnWaitOutstanding(later);                  // tile 0 is in
+  } else {
+    // the per-frame scalars and the global sums, while the first tile is on its way
+    for (int i = threadIdx.x; i < kCmvnWindow; i += kWave * (kCmvnWaves - 1)) { s_alpha[i] = tab->alpha[i]; s_nscale[i] = tab->neg_scale[i]; }
+    if (threadIdx.x < kNumBins) s_g[threadIdx.x] = g[threadIdx.x];
   }
   tile_sync();
 
   float s = 0.0f;                                  // chain wave: cached window sum of feature `lane`
   const int d = lane < kNumBins ? lane : 0;       // lanes 40..63 of the chain wave shadow feature 0
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 g4[kNumBins / 8];                          // writers: the global sums of this wave's five feature quads
+  if (role == 1 || role == 2) {
+#pragma unroll
+    for (int qi = 0; qi < kNumBins / 8; ++qi) g4[qi] = *reinterpret_cast<const f32x4 *>(s_g + 4 * (role - 1 + 2 * qi));
+  }
   for (int i = 0; i <= ntiles; ++i) {
     if (role == 3) {
-      if (i + 1 < ntiles) {
-        fetch(i + 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      // request tile i + kCmvnAhead (its slot held tile i - 2, whose last readers passed the
+      // previous barrier); tile i + 1 must have landed before this iteration's barrier
+      if (i + kCmvnAhead < ntiles) fetch(i + kCmvnAhead);
+      int later = 0;
+#pragma unroll
+      for (int a = 2; a <= kCmvnAhead; ++a) later += pieces(i + a);
+      CmvnWaitOutstanding(later);
     } else if (role == 0) {
       if (i < ntiles) {
-        const float *xin = s_in + (i % 3) * kCmvnTileFloats, *xold = s_old + (i & 1) * kCmvnTileFloats;
+        const float *xin = s_in + (i % kCmvnInSlots) * kCmvnTileFloats, *xold = s_old + (i % kCmvnOldSlots) * kCmvnTileFloats;
         float *sum = s_sum + (i & 1) * kCmvnTileFloats;
         const int t0 = i * kCmvnTile;
         const int nt = T - t0 < kCmvnTile ? T - t0 : kCmvnTile;
@@ -446,25 +493,47 @@ __global__ __launch_bounds__(kWave * kCmvnWaves) void CmvnKernel(
         else walk(std::integral_constant<int, 1>());
       }
     } else if (i >= 1) {
-      // writers: tile i - 1, lane = frame, features split between the two waves
+      // writers: tile i - 1, lane = frame, the ten feature quads split between the two waves
       const int j = i - 1;
-      const float *xin = s_in + (j % 3) * kCmvnTileFloats, *sum = s_sum + (j & 1) * kCmvnTileFloats;
+      const float *xin = s_in + (j % kCmvnInSlots) * kCmvnTileFloats, *sum = s_sum + (j & 1) * kCmvnTileFloats;
       const int t = j * kCmvnTile + lane;
-      if (t < T) {
-        const int tt = t < kCmvnWindow ? t : kCmvnWindow - 1;
-        const float al = s_alpha[tt], ns = s_nscale[tt];
-        for (int dd = role - 1; dd < kNumBins; dd += 2) {
-          const float x = xin[lane * kNumBins + dd];
-          float st = sum[lane * kNumBins + dd];
-          if (t + 1 < kCmvnWindow) st += al * g[dd];          // cmvn.cc:73-92 (count < window)
-          float y = x;
-          y += ns * st;                                       // cmvn.cc:94-101
-          float *row = y0 + (int64_t)dd * ldy;
-          row[left + t] = y;
-          if (t == 0)
-            for (int p = 0; p < left; ++p) row[p] = y;        // am.cc:73 clamp, done at write time
-          if (t == T - 1)
-            for (int p = 0; p < right; ++p) row[left + T + p] = y;   // am.cc:74
+      const int tt = t < kCmvnWindow ? t : kCmvnWindow - 1;
+      const float al = s_alpha[tt], ns = s_nscale[tt];
+      const bool smooth = t + 1 < kCmvnWindow;
+      float *col = y0 + left + t;                               // frame t of feature 0; feature d is d * ldy further
+#pragma unroll
+      for (int qi = 0; qi < kNumBins / 8; ++qi) {
+        const int q = role - 1 + 2 * qi;
+        const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xin + lane * kNumBins + 4 * q);
+        const f32x4 s4 = *reinterpret_cast<const f32x4 *>(sum + lane * kNumBins + 4 * q);
+        float *dst = col + (int64_t)(4 * q) * ldy;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float st = s4[e];
+          if (smooth) st += al * g4[qi][e];                     // cmvn.cc:73-92 (count < window)
+          float y = x4[e];
+          y += ns * st;                                         // cmvn.cc:94-101
+          if (t < T) dst[(int64_t)e * ldy] = y;
+        }
+      }
+      // am.cc:73-75, the edge clamp, done once at write time: the first / last frame replicated
+      // into the left / right pad.  Only the first and the last tile come here; lane = feature.
+      if ((j == 0 && left > 0) || (j == ntiles - 1 && right > 0)) {
+        const int dd = 4 * (role - 1 + 2 * (lane >> 2)) + (lane & 3);     // this wave's 20 features
+        if (lane < kNumBins / 2) {
+          for (int side = 0; side < 2; ++side) {
+            if (side == 0 ? !(j == 0 && left > 0) : !(j == ntiles - 1 && right > 0)) continue;
+            const int te = side == 0 ? 0 : T - 1;                         // the frame to replicate
+            const int lt = te - j * kCmvnTile;
+            const int te_c = te < kCmvnWindow ? te : kCmvnWindow - 1;
+            float st = sum[lt * kNumBins + dd];
+            if (te + 1 < kCmvnWindow) st += s_alpha[te_c] * s_g[dd];
+            float y = xin[lt * kNumBins + dd];
+            y += s_nscale[te_c] * st;
+            float *row = y0 + (int64_t)dd * ldy;
+            if (side == 0) for (int p = 0; p < left; ++p) row[p] = y;
+            else for (int p = 0; p < right; ++p) row[left + T + p] = y;
+          }
         }
       }
     }

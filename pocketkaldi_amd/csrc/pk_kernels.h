@@ -30,6 +30,13 @@ void LaunchLogfTest(const float *x, int n, const FrontendTables *d_tables, float
 // parity-test hook: the kernel's 512-point real FFT (srfft.cc:371-461) on n device frames of 512 floats
 void LaunchSrfft512Test(const float *frames, int n, const FrontendTables *d_tables, float *out, hipStream_t stream);
 
+// The CMVN loader reads whole 64-frame tiles without clamping: every `raw` buffer handed to
+// LaunchCmvn carries kCmvnRawSlack floats of slack behind its last frame and kCmvnRawLead floats
+// in front of its first one (the tile in which the 600-frame window starts to slide reaches
+// 24 frames before frame 0 of its utterance; the values are never used).
+constexpr int kCmvnRawSlack = 64 * kNumBins;
+constexpr int kCmvnRawLead = 1024;
+
 // cmvn.cc:103-115 for a batch: raw [sum T][40] -> feature-major, edge-padded
 // Yt[40][ldy]: utterance u occupies columns pad_base[u] .. pad_base[u]+T+left+right-1,
 // its frame t at column pad_base[u]+left+t, the first/last frame replicated into
