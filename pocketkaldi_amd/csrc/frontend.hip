@@ -393,8 +393,6 @@ __global__ __launch_bounds__(kWave * kCmvnWaves) void CmvnKernel(
   const float *x0 = raw + utts.raw_base[utt] * kNumBins;
   float *y0 = yt + utts.pad_base[utt];
 
-  typedef const __attribute__((address_space(1))) void *GlobalPtr;
-  typedef __attribute__((address_space(3))) void *LdsPtr;
   const int ntiles = (T + kCmvnTile - 1) / kCmvnTile;
   auto slides = [](int i) { return (i + 1) * kCmvnTile > kCmvnWindow; };   // some frame of tile i has t >= 600
   auto pieces = [&](int i) { return i < ntiles ? (slides(i) ? 2 * kCmvnPieces : kCmvnPieces) : 0; };

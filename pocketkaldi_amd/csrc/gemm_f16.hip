@@ -25,8 +25,12 @@
 // by LDS-DMA three half-slabs ahead (the DMA wait + barrier was where the waves sat:
 // 33 % of their lifetime with a one-slab lead).  XOR swizzle on the DMA SOURCE address
 // (linear LDS destination) and on the ds_read_b128 fragment reads (conflict-free).  The
-// two column sub-tiles of a wave take interleaved columns so that an output row is
-// written as packed pairs.
+// two column sub-tiles of a wave take interleaved columns, so a lane holds adjacent output
+// columns; the epilogue stages each wave's rows through the (by then idle) LDS ring and
+// writes them as whole 256-byte row pieces, 16 bytes per lane.
+// (Measured alternative: 256 x 128 tiles, 4 waves, two workgroups per CU -- independent
+// barriers, one tile's epilogue under the other's MFMAs -- 5 % slower: the operand traffic
+// L2 -> LDS per MFMA is 1.5 x, and the chip is power-limited in this mode.)
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
@@ -39,6 +43,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
@@ -76,9 +81,20 @@ __device__ __forceinline__ SplitOut Split(float v) {
   return s;
 }
 
+// Diagnostic build only (tools/ubench/f16_gemm_probe.hip defines PK_F16_STAMPS): s_memtime stamps
+// around the three waits of a step, summed per wave.  In the product build PK_STAMP is nothing.
+#ifdef PK_F16_STAMPS
+#define PK_STAMP(i) do { const long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define PK_STAMP(i) do { } while (0)
+#endif
+
 template <bool RELU, bool LAST>
 __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 slabs
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the ring: 4 x 32 KiB
+#ifdef PK_F16_STAMPS
+  const long long st_kernel = __builtin_amdgcn_s_memtime();
+#endif
 
   // XCD-aware tile walk, as in gemm.hip: contiguous ids per XCD, 4 x 4 super-tiles
   const int nblk = gridDim.x;                       // multiple of 8
@@ -112,14 +128,15 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
   const int q = (lane & 3) ^ ((lr >> 2) & 3);       // logical position landing at this lane's slot
   const uint32_t voff[2] = {(uint32_t)(((int64_t)lr * a.ldx + q * 8) * sizeof(_Float16)),
                             (uint32_t)(((int64_t)2 * lr * a.ldw + q * 8) * sizeof(_Float16))};
-  auto issue_step = [&](int h, int slot) {          // k16 step h: 32 halves of every row
+  // one of this wave's four DMA pieces of k16 step h (32 halves of every row): piece = 2 op + p
+  auto issue_piece = [&](int h, int slot, int piece) {
+    const int op = piece >> 1, p = piece & 1;
+    unsigned char *dst = smem + slot * kHalfSlabBytes + op * kOperandBytes + (wave * 2 + p) * 1024;
+    DmaScalarBase(reinterpret_cast<const float *>(dst), sbase[p][op] + h * 64, voff[op]);
+  };
+  auto issue_step = [&](int h, int slot) {
 #pragma unroll
-    for (int op = 0; op < 2; ++op)
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        unsigned char *dst = smem + slot * kHalfSlabBytes + op * kOperandBytes + (wave * 2 + p) * 1024;
-        DmaScalarBase(reinterpret_cast<const float *>(dst), sbase[p][op] + h * 64, voff[op]);
-      }
+    for (int piece = 0; piece < kPiecesPerWave; ++piece) issue_piece(h, slot, piece);
   };
 
   f32x16 acc[4][2];
@@ -147,8 +164,12 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
   // step is four groups (x = 0..3) of six MFMAs; the A fragments of the next group are
   // fetched while the current group's MFMAs issue.  Before the LAST group of step h:
   // every fragment of step h is in registers (lgkmcnt(0)), this wave's pieces of step
-  // h+1 have landed (counted vmcnt), barrier; then the DMA of step h+4 goes into step h's
-  // buffer and the first fragments of step h+1 are read, all under the last group's MFMAs.
+  // h+1 have landed (counted vmcnt), barrier.  Everything else sits UNDER the MFMA stream (an MFMA
+  // occupies the matrix pipe for 32 cycles and the wave's issue port for 8 of them): the four DMA
+  // pieces of step h+4 -- into step h's buffer, which nobody reads any more -- are spread over the
+  // last group of step h and the first of step h+1, the first fragments of step h+1 are read behind
+  // the first MFMA after the barrier.  (Issued back to back behind the barrier, by both waves of a
+  // SIMD at once, the pieces cost 4-5 %.)
   const int nsteps = a.K / kStepK;
   issue_step(0, 0);
   if (nsteps > 1) issue_step(1, 1);
@@ -175,35 +196,77 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
   read_b(smem, 0);
   read_a(smem, 0, ah[0], al[0]);
 
+#ifdef PK_F16_STAMPS
+  long long st_acc[4] = {0, 0, 0, 0};
+  long long st_last = __builtin_amdgcn_s_memtime();
+  const long long st_begin = st_last;
+#endif
+  auto mfma3 = [&](int x, int y, int cur, int par, int which) {
+    // the three products of one (x, y) tile and k16 step: hi lo, lo hi, hi hi -- in this order
+    if (which == 0) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[par][y], acc[x][y], 0, 0, 0);
+    if (which == 1) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[par][y], acc[x][y], 0, 0, 0);
+    if (which == 2) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[par][y], acc[x][y], 0, 0, 0);
+  };
+  // (Measured and dropped: waves 4-7 issuing their pieces in the second and third group instead,
+  // so that the two waves of a SIMD never issue DMA at the same time: 1-2 % slower.  One barrier
+  // per PAIR of steps, the next pair's DMA issued right behind it: 3.5 % slower -- the barrier wait
+  // of the older wave of a SIMD is the time its partner needs the matrix pipe for, not lost time.)
   auto step = [&](int h, const int par) {             // par = h & 1, compile-time in the body
     const int slot = h & (kRingF16 - 1);
+    const int prev_slot = (h - 1) & (kRingF16 - 1);
     const unsigned char *base = smem + slot * kHalfSlabBytes;
     const unsigned char *next = smem + ((h + 1) & (kRingF16 - 1)) * kHalfSlabBytes;
+    const bool dma_tail = h >= 1 && h + 3 < nsteps;   // pieces 2, 3 of step h + 3 (its pieces 0, 1 went out in step h - 1)
+    const bool dma_head = h + 4 < nsteps;             // pieces 0, 1 of step h + 4
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
       const int cur = x & 1;
       if (x == 3) {
+        PK_STAMP(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0): all of step h is in registers
+        PK_STAMP(1);
         // this wave's pieces of step h+1 landed; steps h+2, h+3 may stay in flight
         if (h + 3 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kPiecesPerWave) : "memory");
         else if (h + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerWave) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PK_STAMP(2);
         __builtin_amdgcn_s_barrier();
+        PK_STAMP(3);
         __builtin_amdgcn_sched_barrier(0);
-        if (h + 4 < nsteps) issue_step(h + 4, slot);  // nobody reads step h's buffer any more
+        mfma3(x, 0, cur, par, 0);
+        __builtin_amdgcn_sched_barrier(0);
         read_b(next, par ^ 1);                        // stale on the last step, unused
         read_a(next, 0, ah[cur ^ 1], al[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(x, 0, cur, par, 1);
+        mfma3(x, 0, cur, par, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (dma_head) issue_piece(h + 4, slot, 0);    // nobody reads step h's buffer any more
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(x, 1, cur, par, 0);
+        mfma3(x, 1, cur, par, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (dma_head) issue_piece(h + 4, slot, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(x, 1, cur, par, 2);
+        __builtin_amdgcn_sched_barrier(0);
       } else {
         read_a(base, x + 1, ah[cur ^ 1], al[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(x, 0, cur, par, 0);
+        mfma3(x, 0, cur, par, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (x == 0 && dma_tail) issue_piece(h + 3, prev_slot, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(x, 0, cur, par, 2);
+        mfma3(x, 1, cur, par, 0);
+        mfma3(x, 1, cur, par, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (x == 0 && dma_tail) issue_piece(h + 3, prev_slot, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(x, 1, cur, par, 2);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int y = 0; y < 2; ++y) {
-        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[par][y], acc[x][y], 0, 0, 0);
-        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[par][y], acc[x][y], 0, 0, 0);
-        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[par][y], acc[x][y], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
     }
   };
   // two steps per trip: the B-fragment parity is then a compile-time constant
@@ -213,32 +276,68 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
     if (h + 1 < nsteps) step(h + 1, 1);
   }
 
+#ifdef PK_F16_STAMPS
+  const long long st_loop_end = __builtin_amdgcn_s_memtime();
+#endif
   // ---- epilogue: acc[x][y][r] = D[M0 + 32x + i'][N0 + y], N0 = n0 + wn*64 + 2 l31,
-  // i' = (r & 3) + 8 (r >> 2) + 4 kg; bias (nnet.cc:32-35), ReLU (nnet.cc:56-58).  The
-  // (N0, N0 + 1) pair sits in one 8-k chunk of the interleaved row: hi pair at chunk*16 +
-  // N0 % 8 halves, lo pair 8 halves further.
+  // i' = (r & 3) + 8 (r >> 2) + 4 kg; bias (nnet.cc:32-35), ReLU (nnet.cc:56-58).
+  // A lane holds two adjacent columns of 64 rows: stored from the registers that is 128 four-byte
+  // stores per lane (the whole epilogue of a tile then costs as much as 18 k16 steps, with the
+  // matrix pipes of the CU idle).  Instead each wave stages 32 rows (one x) at a time in its own
+  // 2 x 8 KiB of the LDS ring -- idle now: every wave passed the last barrier with the last step's
+  // fragments in registers, and all DMA has landed -- as the rows will lie in memory, 256 bytes
+  // per row (64 fp32 logits, or 64 x (hi, lo) halves in chunks of 8), and writes them out 16 bytes
+  // per lane: one store instruction = four whole 256-byte row pieces.  No barrier: a wave reads
+  // back only what it wrote itself.
   const int M0 = m0 + wm * 128, N0 = n0 + wn * 64 + 2 * l31;
   const f32x2 bias = *reinterpret_cast<const f32x2 *>(a.bias + N0);
-  const int pair_off = (N0 >> 3) * 16 + (N0 & 7);
+  unsigned char *stage = smem + wave * (2 * 8192);
+  // byte offset of this lane's pair in a staged row: fp32 pair, or the (hi, lo) halves of chunk l31 / 4
+  const int pair_byte = LAST ? l31 * 8 : (l31 >> 2) * 32 + (l31 & 3) * 4;
+  // this wave's 64 columns start at byte 256 * (column block) of an output row in both formats
+  unsigned char *out_rows = LAST ? reinterpret_cast<unsigned char *>(a.out_f32 + (int64_t)M0 * a.ldo + n0 + wn * 64)
+                                 : reinterpret_cast<unsigned char *>(a.out + (int64_t)M0 * a.ldo + 2 * (n0 + wn * 64));
+  const int64_t row_bytes = a.ldo * (LAST ? (int64_t)sizeof(float) : (int64_t)sizeof(_Float16));
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+  for (int x = 0; x < 4; ++x) {
+    unsigned char *buf = stage + (x & 1) * 8192;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = M0 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * kg;
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
       float v0 = acc[x][0][r] + bias[0], v1 = acc[x][1][r] + bias[1];
       if (RELU) {
         v0 = v0 < 0.0f ? 0.0f : v0;
         v1 = v1 < 0.0f ? 0.0f : v1;
       }
       if (LAST) {
-        *reinterpret_cast<f32x2 *>(a.out_f32 + (int64_t)m * a.ldo + N0) = f32x2{v0, v1};
+        *reinterpret_cast<f32x2 *>(buf + row * 256 + pair_byte) = f32x2{v0, v1};
       } else {
         const SplitOut s0 = Split(v0), s1 = Split(v1);
-        _Float16 *orow = a.out + (int64_t)m * a.ldo + pair_off;
-        *reinterpret_cast<f16x2 *>(orow) = f16x2{s0.hi, s1.hi};
-        *reinterpret_cast<f16x2 *>(orow + 8) = f16x2{s0.lo, s1.lo};
+        *reinterpret_cast<f16x2 *>(buf + row * 256 + pair_byte) = f16x2{s0.hi, s1.hi};
+        *reinterpret_cast<f16x2 *>(buf + row * 256 + pair_byte + 16) = f16x2{s0.lo, s1.lo};
       }
     }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                 // this wave's LDS writes are in
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                       // 8 KiB = 8 x (64 lanes x 16 bytes); lane -> row j*4 + lane/16
+      const int row = j * 4 + (lane >> 4);
+      const f32x4v v = *reinterpret_cast<const f32x4v *>(buf + row * 256 + (lane & 15) * 16);
+      *reinterpret_cast<f32x4v *>(out_rows + (int64_t)(32 * x + row) * row_bytes + (lane & 15) * 16) = v;
+    }
+  }
+#ifdef PK_F16_STAMPS
+  if (lane == 0 && blockIdx.x < 256) {
+    long long *o = pk_f16_stamps + (blockIdx.x * 8 + wave) * 8;
+    o[0] = st_loop_end - st_begin;                       // k loop, cycles
+    o[1] = st_acc[0];                                    // MFMA / issue segments (barrier release -> next lgkm wait)
+    o[2] = st_acc[1];                                    // lgkmcnt(0) wait
+    o[3] = st_acc[2];                                    // vmcnt wait
+    o[4] = st_acc[3];                                    // barrier wait
+    o[5] = st_begin - st_kernel;                         // prologue (start -> first fragments requested)
+    o[6] = __builtin_amdgcn_s_memtime() - st_loop_end;   // epilogue (stores issued)
+  }
+#endif
 }
 
 // fp32 -> interleaved (hi, lo) fp16 rows.  in: element (r, c) at in[r * stride_r + c *
