@@ -468,13 +468,19 @@ __global__ __launch_bounds__(kWave * kCmvnWaves) void CmvnKernel(
         constexpr int kBlk = 8;
         auto walk = [&](auto mode) {
           constexpr int MODE = decltype(mode)::value;
-          for (int u0 = 0; u0 < nt; u0 += kBlk) {
-            float xs[kBlk], xo[kBlk];
+          float xs[kBlk], xo[kBlk], nxs[kBlk], nxo[kBlk];
+          auto fetch_block = [&](int u0, float (&a)[kBlk], float (&b)[kBlk]) {
 #pragma unroll
             for (int v = 0; v < kBlk; ++v) {
-              xs[v] = xin[(u0 + v) * kNumBins + d];
-              if (MODE != 0) xo[v] = xold[(u0 + v) * kNumBins + d];
+              a[v] = xin[(u0 + v) * kNumBins + d];
+              if (MODE != 0) b[v] = xold[(u0 + v) * kNumBins + d];
             }
+          };
+          fetch_block(0, xs, xo);
+          for (int u0 = 0; u0 < nt; u0 += kBlk) {
+            // the next block's operands are requested before this block's chain starts: their
+            // LDS latency (a hundred cycles, once per eight frames) runs under the arithmetic
+            if (u0 + kBlk < kCmvnTile) fetch_block(u0 + kBlk, nxs, nxo);
 #pragma unroll
             for (int v = 0; v < kBlk; ++v) {
               double acc = s;                                 // cmvn.cc:44-52
@@ -484,6 +490,8 @@ __global__ __launch_bounds__(kWave * kCmvnWaves) void CmvnKernel(
               s = static_cast<float>(acc);                    // cmvn.cc:66-70
               sum[(u0 + v) * kNumBins + d] = s;
             }
+#pragma unroll
+            for (int v = 0; v < kBlk; ++v) { xs[v] = nxs[v]; xo[v] = nxo[v]; }
           }
         };
         if (t0 + kCmvnTile <= kCmvnWindow) walk(std::integral_constant<int, 0>());

@@ -253,6 +253,28 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
     if (sd[j] >= a.splice_dim) { sd[j] -= a.splice_dim; ++sc[j]; }
   };
 
+  // The bias values are fetched in one batch (a per-element runtime select makes hipcc branch
+  // around every load and wait for each one).  The small tiles (S = 1: launches of a few
+  // microseconds, one or two waves per SIMD) request them here, in front of the k loop, so that
+  // the round trip to L2 is not added to the epilogue; the big tiles have no registers to park
+  // them in (three workgroups per CU) and other workgroups to cover for them.
+  const int I0 = i0 + wi * (32 * S), J0 = j0 + wj * (32 * S);
+  float bj[S];
+  float bi[S][16];
+  auto load_bias = [&]() {
+    if (BIAS_J) {
+#pragma unroll
+      for (int y = 0; y < S; ++y) bj[y] = a.bias[J0 + S * l31 + y];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int x = 0; x < S; ++x)
+          bi[x][r] = a.bias[I0 + S * ((r & 3) + 8 * (r >> 2) + 4 * half) + x];
+    }
+  };
+  if (S == 1) load_bias();
+
   // The slabs that still have DMA to issue and the last kAhead ones run through two copies of
   // the body, so that "is there a slab to fetch" is never a run-time predicate in the loop
   // (hipcc turned it into vector compares that write a register the MFMAs are still reading).
@@ -334,21 +356,8 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
   // ---- epilogue.  Accumulator acc[x][y], register r, lane (l31, half) holds
   // D[I0 + S i' + x][J0 + S l31 + y] with i' = (r & 3) + 8 (r >> 2) + 4 half: the y values
   // are adjacent in memory, so (S = 2) a row is written as 32 lanes x 8 bytes = 256
-  // contiguous bytes per store.  The bias values are fetched in one batch (a per-element
-  // runtime select makes hipcc branch around every load and wait for each one).
-  const int I0 = i0 + wi * (32 * S), J0 = j0 + wj * (32 * S);
-  float bj[S];
-  float bi[S][16];
-  if (BIAS_J) {
-#pragma unroll
-    for (int y = 0; y < S; ++y) bj[y] = a.bias[J0 + S * l31 + y];
-  } else {
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-#pragma unroll
-      for (int x = 0; x < S; ++x)
-        bi[x][r] = a.bias[I0 + S * ((r & 3) + 8 * (r >> 2) + 4 * half) + x];
-  }
+  // contiguous bytes per store.
+  if (S == 2) load_bias();        // (S = 1 fetched it before the k loop)
 #pragma unroll
   for (int x = 0; x < S; ++x) {
     float *obase = a.out + (int64_t)(I0 + S * 4 * half + x) * a.ldo + J0 + S * l31;

@@ -36,3 +36,23 @@ t0 = time.perf_counter()
 for _ in range(50):
     pk.Decodable(am, 0.1, feats).destroy()
 print("pk_decodable_init (H2D feats, nnet, D2H 12 MB log_prob): %.3f ms" % ((time.perf_counter() - t0) / 50 * 1e3))
+
+# Two independent utterances on two streams: do their kernels share the CUs and hide each other's
+# launch ramps?  (the premise of splitting ONE utterance's frames into two pipelined halves)
+bs2 = pk.BatchScorer(am, synth.global_cmvn_stats(), 1, len(w))
+bs2.set_waves([synth.utterance(1, 10.0)])
+bs.enable_timing(False)
+for _ in range(10):
+    bs.score(0.1, sync=False); bs2.score(0.1, sync=False)
+bs.synchronize(); bs2.synchronize()
+t0 = time.perf_counter()
+for _ in range(n):
+    bs.score(0.1, sync=False); bs2.score(0.1, sync=False)
+bs.synchronize(); bs2.synchronize()
+print("two utterances in flight on two streams: %.3f ms per PAIR (one alone, back to back: %.3f ms each)"
+      % ((time.perf_counter() - t0) / n * 1e3, async_ms))
+t0 = time.perf_counter()
+for _ in range(n):
+    bs.score(0.1, sync=False); bs2.score(0.1, sync=False)
+    bs.synchronize(); bs2.synchronize()
+print("same, synchronised after every pair: %.3f ms per pair" % ((time.perf_counter() - t0) / n * 1e3))

@@ -1,6 +1,15 @@
 #!/usr/bin/env python3
 """Turn the raw output of tools/profile_gpu.sh (gpurun_out/prof/) into the committed summaries
-under profiles/:  usage: tools/make_profiles.py r01"""
+under profiles/:   usage: tools/make_profiles.py r02
+
+Per section found (S = headline workload, W = BASELINE configs[4] wide model, B1 = configs[1]):
+  rNN_<sec>_<mode>_kernel_stats.csv        rocprofv3 --kernel-trace --stats summary, verbatim
+  rNN_<sec>_<mode>_bench_under_rocprof.json the bench line of that same run
+  rNN_<sec>_pmc_traffic.json               FETCH_SIZE / WRITE_SIZE passes -> HBM bytes per launch
+  rNN_<sec>_pmc_mfma.json                  MFMA-busy passes (+ effective clock from GRBM_GUI_ACTIVE)
+  rNN_B1_kernel_stats.csv, rNN_B1_probe.txt
+  rNN_bench.json                           the plain benchmark line
+"""
 import collections
 import csv
 import glob
@@ -15,10 +24,12 @@ SRC = "gpurun_out/prof"
 DST = "profiles"
 
 
-def one(pattern):
+def one(pattern, required=True):
     hits = glob.glob(os.path.join(SRC, pattern), recursive=True)
     if not hits:
-        raise SystemExit("missing " + pattern)
+        if required:
+            raise SystemExit("missing " + pattern)
+        return None
     return hits[0]
 
 
@@ -28,56 +39,101 @@ def short(name):
 
 
 def counters(d):
-    """{(kernel, grid): {counter: [values per dispatch]}} of one PMC pass"""
+    """{(kernel, grid): {counter: [values per dispatch]}, ...} and per-dispatch durations of one PMC pass"""
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     per = collections.defaultdict(lambda: collections.defaultdict(float))
+    dur = {}
     for r in csv.DictReader(open(one(d + "/**/*counter_collection.csv"))):
-        per[(r["Dispatch_Id"], short(r["Kernel_Name"]), int(r["Grid_Size"]))][r["Counter_Name"]] += float(r["Counter_Value"])
-    for (_, k, g), c in per.items():
+        key = (r["Dispatch_Id"], short(r["Kernel_Name"]), int(r["Grid_Size"]))
+        per[key][r["Counter_Name"]] += float(r["Counter_Value"])
+        dur[key] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+    durs = collections.defaultdict(list)
+    for (did, k, g), c in per.items():
         for name, v in c.items():
             agg[(k, g)][name].append(v)
-    return agg
+        durs[(k, g)].append(dur[(did, k, g)])
+    return agg, durs
 
 
-for mode in ("f32", "f16x3"):
-    shutil.copy(one(mode + "/**/*kernel_stats.csv"), os.path.join(DST, "%s_%s_kernel_stats.csv" % (tag, mode)))
-    line = open(os.path.join(SRC, mode + "_bench.json")).read().strip().splitlines()[-1]
-    json.dump(json.loads(line), open(os.path.join(DST, "%s_%s_bench_under_rocprof.json" % (tag, mode)), "w"), indent=1)
-line = open(os.path.join(SRC, "bench.json")).read().strip().splitlines()[-1]
-json.dump(json.loads(line), open(os.path.join(DST, tag + "_bench.json"), "w"), indent=1)
+def bench_line(path):
+    line = open(path).read().strip().splitlines()[-1]
+    return json.loads(line)
 
-fetch, write = counters("pmc_fetch"), counters("pmc_write")
-kernels, gemm_bytes, gemm_n = [], 0.0, 0
-for key in sorted(fetch):
-    f = fetch[key]["FETCH_SIZE"]
-    w = write.get(key, {}).get("WRITE_SIZE", [0.0])
-    fk, wk = sum(f) / len(f), sum(w) / len(w)
-    hbm = 2.0 * fk * 1024 + wk * 1024
-    kernels.append({"kernel": key[0], "grid_threads": key[1], "dispatches_sampled": len(f),
-                    "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes_per_launch_corrected": hbm})
-    if key[0].startswith("GemmKernel"):
-        gemm_bytes += hbm * len(f)
-        gemm_n += len(f)
-json.dump({
-    "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 1 --warmup 1 "
-            "--no-cpu-baseline --no-other-precision --no-other-configs` (model S, 256 utt x 10 s, f32; tools/profile_gpu.sh). "
-            "Counters are in KB. gfx950 correction per MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts 128-B requests at "
-            "64 B for wide coalesced reads, so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE is exact.",
-    "kernels": kernels, "gemm_avg_hbm_bytes_per_launch": gemm_bytes / max(gemm_n, 1), "gemm_launches_sampled": gemm_n},
-    open(os.path.join(DST, tag + "_pmc_traffic.json"), "w"), indent=1)
 
-out = {"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE ... (own pass, tools/profile_gpu.sh). "
-               "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CU_CYCLES * 4 SIMDs); GRBM_GUI_ACTIVE is summed over the 8 XCDs.",
-       "f32": [], "f16x3": []}
-for mode, d in (("f32", "pmc_mfma"), ("f16x3", "pmc_mfma_f16")):
-    for key, c in sorted(counters(d).items()):
-        if "Gemm" not in key[0]:
+wrote = []
+for sec in ("S", "W"):
+    for mode in ("f32", "f16x3"):
+        stats = one("%s_%s/**/*kernel_stats.csv" % (sec, mode), required=False)
+        if not stats:
             continue
-        avg = {k: sum(v) / len(v) for k, v in c.items()}
-        row = {"kernel": key[0], "grid_threads": key[1], "dispatches_sampled": len(next(iter(c.values())))}
-        row.update(avg)
-        if avg.get("SQ_BUSY_CU_CYCLES"):
-            row["mfma_busy"] = avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (avg["SQ_BUSY_CU_CYCLES"] * 4.0)
-        out[mode].append(row)
-json.dump(out, open(os.path.join(DST, tag + "_pmc_mfma.json"), "w"), indent=1)
-print("wrote", sorted(os.listdir(DST)))
+        shutil.copy(stats, os.path.join(DST, "%s_%s_%s_kernel_stats.csv" % (tag, sec, mode)))
+        json.dump(bench_line(os.path.join(SRC, "%s_%s_bench.json" % (sec, mode))),
+                  open(os.path.join(DST, "%s_%s_%s_bench_under_rocprof.json" % (tag, sec, mode)), "w"), indent=1)
+        wrote += ["%s_%s kernel stats" % (sec, mode)]
+    # HBM traffic per launch
+    traffic = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 1 --warmup 1 "
+                       "--no-cpu-baseline --no-other-precision --no-other-configs --no-host-endpoints%s [--precision f16x3]` "
+                       "(256 utt x 10 s; tools/profile_gpu.sh). Counters are in KB. gfx950 correction per MI355X_MICROARCH.md (HBM "
+                       "section): FETCH_SIZE counts 128-B requests at 64 B for wide coalesced reads, so read bytes = 2 x FETCH_SIZE x "
+                       "1024; WRITE_SIZE is exact." % (" --model W" if sec == "W" else "")}
+    mfma = {"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY "
+                    "SQ_LDS_BANK_CONFLICT (own pass, tools/profile_gpu.sh). mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CU_CYCLES "
+                    "* 4 SIMDs); effective_clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration (MI355X_MICROARCH.md, DVFS "
+                    "give-back); mfma_rate_frac_of_2p4ghz_peak = mfma_busy * clock / 2.4."}
+    have = False
+    for mode in ("f32", "f16x3"):
+        if not one("%s_pmc_fetch_%s/**/*counter_collection.csv" % (sec, mode), required=False):
+            continue
+        have = True
+        fetch, _ = counters("%s_pmc_fetch_%s" % (sec, mode))
+        write, _ = counters("%s_pmc_write_%s" % (sec, mode))
+        kernels, gemm_bytes, gemm_n = [], 0.0, 0
+        for key in sorted(fetch):
+            f = fetch[key]["FETCH_SIZE"]
+            w = write.get(key, {}).get("WRITE_SIZE", [0.0])
+            fk, wk = sum(f) / len(f), sum(w) / len(w)
+            hbm = 2.0 * fk * 1024 + wk * 1024
+            kernels.append({"kernel": key[0], "grid_threads": key[1], "dispatches_sampled": len(f),
+                            "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes_per_launch_corrected": hbm})
+            if key[0].startswith("Gemm"):
+                gemm_bytes += hbm * len(f)
+                gemm_n += len(f)
+        traffic[mode] = {"kernels": kernels, "gemm_avg_hbm_bytes_per_launch": gemm_bytes / max(gemm_n, 1),
+                         "gemm_launches_sampled": gemm_n}
+        agg, durs = counters("%s_pmc_mfma_%s" % (sec, mode))
+        rows = []
+        for key, c in sorted(agg.items()):
+            if "Gemm" not in key[0]:
+                continue
+            avg = {k: sum(v) / len(v) for k, v in c.items()}
+            row = {"kernel": key[0], "grid_threads": key[1], "dispatches_sampled": len(next(iter(c.values()))),
+                   "avg_duration_us": sum(durs[key]) / len(durs[key]) * 1e6}
+            row.update(avg)
+            if avg.get("SQ_BUSY_CU_CYCLES"):
+                row["mfma_busy"] = avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (avg["SQ_BUSY_CU_CYCLES"] * 4.0)
+            if avg.get("GRBM_GUI_ACTIVE"):
+                row["effective_clock_ghz"] = avg["GRBM_GUI_ACTIVE"] / 8.0 / (row["avg_duration_us"] * 1e-6) / 1e9
+                if "mfma_busy" in row:
+                    row["mfma_rate_frac_of_2p4ghz_peak"] = row["mfma_busy"] * row["effective_clock_ghz"] / 2.4
+            rows.append(row)
+        mfma[mode] = rows
+    if have:
+        if sec == "S" and "f32" in traffic:       # bench.py reads this key
+            traffic["gemm_avg_hbm_bytes_per_launch"] = traffic["f32"]["gemm_avg_hbm_bytes_per_launch"]
+        json.dump(traffic, open(os.path.join(DST, "%s_%s_pmc_traffic.json" % (tag, sec)), "w"), indent=1)
+        json.dump(mfma, open(os.path.join(DST, "%s_%s_pmc_mfma.json" % (tag, sec)), "w"), indent=1)
+        wrote += ["%s pmc" % sec]
+
+b1 = one("B1/**/*kernel_stats.csv", required=False)
+if b1:
+    shutil.copy(b1, os.path.join(DST, tag + "_B1_kernel_stats.csv"))
+    keep = [l for l in open(os.path.join(SRC, "B1_probe.log")) if not re.match(r"^[EWI]\d{8} ", l) and not l.startswith("/opt")]
+    open(os.path.join(DST, tag + "_B1_probe.txt"), "w").write("".join(keep))
+    wrote += ["B1"]
+if os.path.exists(os.path.join(SRC, "bench.json")):
+    json.dump(bench_line(os.path.join(SRC, "bench.json")), open(os.path.join(DST, tag + "_bench.json"), "w"), indent=1)
+    wrote += ["bench"]
+# bench.py's roofline.traffic reads profiles/rNN_pmc_traffic.json (newest round first)
+if os.path.exists(os.path.join(DST, tag + "_S_pmc_traffic.json")):
+    shutil.copy(os.path.join(DST, tag + "_S_pmc_traffic.json"), os.path.join(DST, tag + "_pmc_traffic.json"))
+print("wrote", wrote, sorted(f for f in os.listdir(DST) if f.startswith(tag)))
