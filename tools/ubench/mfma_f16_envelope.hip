@@ -29,13 +29,16 @@ __global__ __launch_bounds__(512, 2) void K(const f16x8 *__restrict__ rnd, float
   for (int x = 0; x < 4; ++x) for (int y = 0; y < 2; ++y) acc32[x][y] = f32x16{0};
   for (int x = 0; x < 8; ++x) for (int y = 0; y < 4; ++y) acc16[x][y] = f32x4{0};
   const long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  f16x8 na[8], nb[4];
   for (int it = 0; it < iters; ++it) {
-    if (SRC == 1) {                      // 12 ds_read_b128 per k32 of the wave tile, like the GEMM's fragment traffic
-      const int base = (it * 64 + lane) & 2047;
+    if (SRC == 1) {                      // 12 ds_read_b128 per k32 of the wave tile, like the GEMM's fragment
+      // traffic; software-pipelined: the next iteration's operands are requested before this one's MFMAs
+      const int base = ((it + 1) * 64 + lane) & 2047;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) a[i] = lds[(base + i * 64) & 4095];
+      for (int i = 0; i < 8; ++i) na[i] = lds[(base + i * 64) & 4095];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) b[i] = lds[(base + 2048 + i * 64) & 4095];
+      for (int i = 0; i < 4; ++i) nb[i] = lds[(base + 2048 + i * 64) & 4095];
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (SHAPE == 0) {
       // one k32 of a 128 x 64 tile: 4 x 2 tiles x 2 k16 steps = 16 MFMAs of 32 cycles
@@ -53,6 +56,13 @@ __global__ __launch_bounds__(512, 2) void K(const f16x8 *__restrict__ rnd, float
 #pragma unroll
         for (int y = 0; y < 4; ++y)
           acc16[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[x], b[y], acc16[x][y], 0, 0, 0);
+    }
+    if (SRC == 1) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = na[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b[i] = nb[i];
     }
   }
   const long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
