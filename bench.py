@@ -414,7 +414,7 @@ def main():
             "config": {"workload": "%d utterances x %.0f s 16 kHz per GPU (BASELINE configs[2]; x8 = configs[3]), "
                                    "440 -> %d x %d ReLU -> %d softmax, fbank+CMVN+nnet, PCM resident in HBM"
                                    % (args.batch, args.seconds, nh, hidden, pdfs),
-                       "model": args.model, "softmax": args.softmax, "utterances_per_gpu": args.batch,
+                       "acoustic_model": args.model, "softmax": args.softmax, "utterances_per_gpu": args.batch,
                        "frames_per_gpu_per_step": int(frames_per_step),
                        "parallelism": "utterance-sharded x%d, weights broadcast once (%s)" % (
                            world, "RCCL" if args.backend == "nccl" else "gloo rehearsal")},

@@ -532,9 +532,22 @@ struct Arena {
   bool batch_alive;
 };
 std::vector<Arena> g_arenas;
+// Address ranges of arenas already released.  A view that outlived every count (one of an EARLIER
+// fetch_all, destroyed after a later fetch_all's views and the batch are gone) must still not reach
+// free(): its pointer was never malloc()'d.  If malloc() later hands out memory inside such a
+// range, that block is leaked by pk_decodable_destroy instead of freed -- the safe direction.
+std::vector<std::pair<const char *, const char *>> g_retired;
+void RetireRange(const Arena &a) {          // g_arena_mu held
+  if (g_retired.size() >= 256) g_retired.erase(g_retired.begin());
+  g_retired.emplace_back(a.lo, a.hi);
+}
 
 void RegisterArena(void *p, size_t bytes) {
   std::lock_guard<std::mutex> g(g_arena_mu);
+  const char *lo = static_cast<char *>(p), *hi = lo + bytes;
+  for (size_t i = 0; i < g_retired.size();)     // the address space is in use again
+    if (g_retired[i].first < hi && lo < g_retired[i].second) g_retired.erase(g_retired.begin() + i);
+    else ++i;
   g_arenas.push_back(Arena{static_cast<char *>(p), static_cast<char *>(p) + bytes, 0, true});
 }
 void SetArenaViews(const void *p, int views) {
@@ -550,7 +563,7 @@ void RetireArena(void *p) {
     for (size_t i = 0; i < g_arenas.size(); ++i)
       if (g_arenas[i].lo == p) {
         g_arenas[i].batch_alive = false;
-        if (g_arenas[i].live_views <= 0) { g_arenas.erase(g_arenas.begin() + i); release = true; }
+        if (g_arenas[i].live_views <= 0) { RetireRange(g_arenas[i]); g_arenas.erase(g_arenas.begin() + i); release = true; }
         break;
       }
   }
@@ -568,9 +581,12 @@ bool ReleaseArenaView(const void *p) {
       if (static_cast<const char *>(p) < a.lo || static_cast<const char *>(p) >= a.hi) continue;
       found = true;
       if (a.live_views > 0) --a.live_views;
-      if (!a.batch_alive && a.live_views == 0) { release = a.lo; g_arenas.erase(g_arenas.begin() + i); }
+      if (!a.batch_alive && a.live_views == 0) { release = a.lo; RetireRange(a); g_arenas.erase(g_arenas.begin() + i); }
       break;
     }
+    if (!found)
+      for (const auto &r : g_retired)
+        if (static_cast<const char *>(p) >= r.first && static_cast<const char *>(p) < r.second) { found = true; break; }
   }
   if (release) hipHostFree(release);
   return found;

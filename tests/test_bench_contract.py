@@ -23,7 +23,7 @@ def test_bench_line_has_the_contract_keys():
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
-    assert "workload" in d["config"] and "model" in d["config"]
+    assert "workload" in d["config"] and "acoustic_model" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"):
         assert k in r, k
