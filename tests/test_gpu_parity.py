@@ -860,3 +860,23 @@ def test_one_model_shared_by_host_threads():
     assert not errs
     for a, b in zip(got, want):
         assert bits_equal(a, b)
+
+
+def test_more_utterances_than_cus():
+    """300 short utterances: the CMVN kernel (one workgroup per utterance, 117 KiB of LDS: one per CU)
+    needs more than one round of workgroups; features and log-likelihoods per utterance as alone."""
+    layers, prior, L, R, tid2pdf = tiny_model()
+    g = synth.global_cmvn_stats()
+    rng = np.random.default_rng(300)
+    lens = [int(rng.integers(400, 12000)) for _ in range(300)]
+    waves = [synth.utterance(2000 + i, 0.75)[:n] for i, n in enumerate(lens)]
+    am = pk.AcousticModel(layers, prior, L, R, tid2pdf).set_softmax("reference")
+    bs = pk.BatchScorer(am, g, len(waves), sum(lens))
+    bs.set_waves(waves)
+    bs.score(0.1)
+    nn, fb = O.Nnet(layers), O.Fbank()
+    for u in (0, 1, 127, 255, 256, 257, 299):
+        f = fb.compute(waves[u])
+        c = O.cmvn(g, f)
+        assert bits_equal(bs.fetch_fbank(u), f) and bits_equal(bs.fetch_cmvn(u), c)
+        assert bits_equal(bs.fetch(u).log_prob(), nn.am_compute(c, prior, L, R, 0.1))
