@@ -459,39 +459,30 @@ __global__ __launch_bounds__(kWave * kCmvnWaves) void CmvnKernel(
         const float *xin = s_in + (i % kCmvnInSlots) * kCmvnTileFloats, *xold = s_old + (i % kCmvnOldSlots) * kCmvnTileFloats;
         float *sum = s_sum + (i & 1) * kCmvnTileFloats;
         const int t0 = i * kCmvnTile;
-        const int nt = T - t0 < kCmvnTile ? T - t0 : kCmvnTile;
-        // blocks of 8 frames: the LDS operands of a block are fetched first (they do not
-        // depend on the recurrence), so the serial chain is arithmetic only.  Whole blocks
-        // always: frames past the end of the utterance compute values nobody reads (their
-        // slots of the tile exist), and lanes 40..63 store feature 0's value on top of lane 0's.
+        // The LDS operands of the WHOLE tile -- 64 values of x, and of x[t - 600] once the window
+        // slides -- are requested up front, 128 registers; then the serial chain is arithmetic plus
+        // one LDS store per frame.  (In blocks of 8 with the next block requested early, hipcc still
+        // put a full lgkmcnt(0) in front of every block -- the counter has 4 bits, 16 younger
+        // operations were in flight -- and the tile cost twice the chain's own time.)  Whole tiles
+        // always: frames past the end of the utterance compute values nobody reads (their slots of
+        // the tile exist), and lanes 40..63 store feature 0's value on top of lane 0's.
         // MODE 0: no frame of the tile has left the window yet; 2: all have; 1: mixed.
-        constexpr int kBlk = 8;
         auto walk = [&](auto mode) {
           constexpr int MODE = decltype(mode)::value;
-          float xs[kBlk], xo[kBlk], nxs[kBlk], nxo[kBlk];
-          auto fetch_block = [&](int u0, float (&a)[kBlk], float (&b)[kBlk]) {
+          float xs[kCmvnTile], xo[MODE != 0 ? kCmvnTile : 1];
 #pragma unroll
-            for (int v = 0; v < kBlk; ++v) {
-              a[v] = xin[(u0 + v) * kNumBins + d];
-              if (MODE != 0) b[v] = xold[(u0 + v) * kNumBins + d];
-            }
-          };
-          fetch_block(0, xs, xo);
-          for (int u0 = 0; u0 < nt; u0 += kBlk) {
-            // the next block's operands are requested before this block's chain starts: their
-            // LDS latency (a hundred cycles, once per eight frames) runs under the arithmetic
-            if (u0 + kBlk < kCmvnTile) fetch_block(u0 + kBlk, nxs, nxo);
+          for (int v = 0; v < kCmvnTile; ++v) {
+            xs[v] = xin[v * kNumBins + d];
+            if (MODE != 0) xo[v] = xold[v * kNumBins + d];
+          }
 #pragma unroll
-            for (int v = 0; v < kBlk; ++v) {
-              double acc = s;                                 // cmvn.cc:44-52
-              acc += xs[v];
-              if (MODE == 2 || (MODE == 1 && t0 + u0 + v >= kCmvnWindow))
-                acc += -1.0 * static_cast<double>(xo[v]);     // cmvn.cc:58-64
-              s = static_cast<float>(acc);                    // cmvn.cc:66-70
-              sum[(u0 + v) * kNumBins + d] = s;
-            }
-#pragma unroll
-            for (int v = 0; v < kBlk; ++v) { xs[v] = nxs[v]; xo[v] = nxo[v]; }
+          for (int v = 0; v < kCmvnTile; ++v) {
+            double acc = s;                                 // cmvn.cc:44-52
+            acc += xs[v];
+            if (MODE == 2 || (MODE == 1 && t0 + v >= kCmvnWindow))
+              acc += -1.0 * static_cast<double>(xo[MODE != 0 ? v : 0]);     // cmvn.cc:58-64
+            s = static_cast<float>(acc);                    // cmvn.cc:66-70
+            sum[v * kNumBins + d] = s;
           }
         };
         if (t0 + kCmvnTile <= kCmvnWindow) walk(std::integral_constant<int, 0>());
