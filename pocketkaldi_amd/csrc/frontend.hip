@@ -85,22 +85,8 @@ __device__ __forceinline__ void LButterfly(f32x2 *z, int base, int n, const floa
 
 // The constant tables of the front-end, copied once per workgroup into LDS (the
 // kernel is latency-bound: a table value fetched from L2 inside every FFT pass costs
-// more than the butterfly it feeds).  Mel weights are packed back to back.
-struct LdsTables {
-  double logf_tab[kLogfTableDoubles];
-  float window[kFrameLength];
-  float tw[kTwFloats];
-  float post_re[kFftCplx / 2 + 1];
-  float post_im[kFftCplx / 2 + 1];
-  float mel_w[kMelPacked];
-  short mel_off[kNumBins];
-  short mel_len[kNumBins];
-  short mel_base[kNumBins];
-  short tw_off[kLogCplx + 1];
-  short pass_start[kNumPasses + 1];
-  unsigned char blk_off[kMaxBlocks + 1];
-  unsigned char bitrev[kFftCplx];
-};
+// more than the butterfly it feeds).  Layout and narrowing are the host's (pk_tables.h).
+typedef FrontendLdsImage LdsTables;
 
 // Per-wave work area: one frame.
 struct FrameLds {
@@ -133,22 +119,25 @@ __device__ __forceinline__ void FftPass(f32x2 *z, int lane, const LdsTables &tab
   WaveSync();
 }
 
+// One flat copy, 16 bytes per lane, every load in flight before the first store.
 __device__ __forceinline__ void CopyTablesToLds(LdsTables &tab, const FrontendTables *__restrict__ gtab) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int kPieces = (int)(sizeof(LdsTables) / 16);
+  constexpr int kPerThread = (kPieces + 63) / 64;            // enough for the smallest workgroup (one wave)
+  const u32x4 *src = reinterpret_cast<const u32x4 *>(&gtab->lds);
+  u32x4 *dst = reinterpret_cast<u32x4 *>(&tab);
   const int tid = threadIdx.x, nt = blockDim.x;
-  for (int i = tid; i < kLogfTableDoubles; i += nt) tab.logf_tab[i] = gtab->logf_tab[i];
-  for (int i = tid; i < kFrameLength; i += nt) tab.window[i] = gtab->window[i];
-  for (int i = tid; i < kTwFloats; i += nt) tab.tw[i] = gtab->tw[i];
-  for (int i = tid; i <= kFftCplx / 2; i += nt) { tab.post_re[i] = gtab->post_re[i]; tab.post_im[i] = gtab->post_im[i]; }
-  for (int i = tid; i < kMelPacked; i += nt) tab.mel_w[i] = gtab->mel_packed[i];
-  for (int i = tid; i < kNumBins; i += nt) {
-    tab.mel_off[i] = (short)gtab->mel_off[i];
-    tab.mel_len[i] = (short)gtab->mel_len[i];
-    tab.mel_base[i] = (short)gtab->mel_base[i];
+  u32x4 v[kPerThread];
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    const int i = tid + k * nt;
+    if (i < kPieces) v[k] = src[i];
   }
-  for (int i = tid; i <= kLogCplx; i += nt) tab.tw_off[i] = (short)gtab->tw_off[i];
-  for (int i = tid; i <= kNumPasses; i += nt) tab.pass_start[i] = (short)gtab->pass_start[i];
-  for (int i = tid; i <= kMaxBlocks; i += nt) tab.blk_off[i] = (unsigned char)gtab->blk_off[i];
-  for (int i = tid; i < kFftCplx; i += nt) tab.bitrev[i] = (unsigned char)gtab->bitrev[i];
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    const int i = tid + k * nt;
+    if (i < kPieces) dst[i] = v[k];
+  }
 }
 
 // srfft.cc:95-237: the 256-point complex split-radix DIF on the interleaved frame in LDS, one

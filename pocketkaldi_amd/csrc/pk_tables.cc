@@ -149,6 +149,28 @@ int BuildFrontendTables(FrontendTables *t) {
     for (int j = 0; j < len; ++j) t->mel_packed[packed + j] = w[first + j];
     packed += len;
   }
+
+  // ---- the packed LDS image of the kernels
+  FrontendLdsImage &L = t->lds;
+  memcpy(L.logf_tab, t->logf_tab, sizeof(L.logf_tab));
+  memcpy(L.window, t->window, sizeof(L.window));
+  memcpy(L.tw, t->tw, sizeof(L.tw));
+  memcpy(L.post_re, t->post_re, sizeof(L.post_re));
+  memcpy(L.post_im, t->post_im, sizeof(L.post_im));
+  memcpy(L.mel_w, t->mel_packed, sizeof(L.mel_w));
+  for (int i = 0; i < kNumBins; ++i) {
+    if (t->mel_off[i] > 32767 || t->mel_len[i] > 32767 || t->mel_base[i] > 32767) return -1;
+    L.mel_off[i] = (short)t->mel_off[i];
+    L.mel_len[i] = (short)t->mel_len[i];
+    L.mel_base[i] = (short)t->mel_base[i];
+  }
+  for (int i = 0; i <= kLogCplx; ++i) L.tw_off[i] = (short)t->tw_off[i];
+  for (int i = 0; i <= kNumPasses; ++i) L.pass_start[i] = (short)t->pass_start[i];
+  for (int i = 0; i <= kMaxBlocks; ++i) {
+    if (t->blk_off[i] < 0 || t->blk_off[i] > 255) return -1;
+    L.blk_off[i] = (unsigned char)t->blk_off[i];
+  }
+  for (int i = 0; i < kFftCplx; ++i) L.bitrev[i] = (unsigned char)t->bitrev[i];
   return 0;
 }
 

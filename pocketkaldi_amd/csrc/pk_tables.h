@@ -36,6 +36,26 @@ constexpr int kTwFloats = 6 * (4 + 8 + 16 + 32 + 64);
 constexpr int kMelMaxLen = 64;         // longest triangle (checked at build time)
 constexpr int kMelPacked = 640;        // all triangles back to back (sum of lengths, checked)
 
+// What the front-end kernels keep in LDS, in the layout they keep it in: built once on the host
+// and copied flat, 16 bytes per lane (ten separate table copies, each a round trip to L2, were a
+// third of the fbank kernel's time on a single utterance).
+struct alignas(16) FrontendLdsImage {
+  double logf_tab[32];
+  float window[kFrameLength];
+  float tw[kTwFloats];
+  float post_re[kFftCplx / 2 + 1];
+  float post_im[kFftCplx / 2 + 1];
+  float mel_w[kMelPacked];
+  short mel_off[kNumBins];
+  short mel_len[kNumBins];
+  short mel_base[kNumBins];
+  short tw_off[kLogCplx + 1];
+  short pass_start[kNumPasses + 1];
+  unsigned char blk_off[kMaxBlocks + 1];
+  unsigned char bitrev[kFftCplx];
+};
+static_assert(sizeof(FrontendLdsImage) % 16 == 0, "copied in 16-byte pieces");
+
 struct FrontendTables {
   double logf_tab[32];                 // pk_logf.h: 16 x (1/c, log c) of the C library's logf
   float window[kFrameLength];
@@ -53,6 +73,7 @@ struct FrontendTables {
   int32_t mel_maxlen;
   int32_t mel_base[kNumBins];          // start of bin b's weights in mel_packed
   float mel_packed[kMelPacked];
+  FrontendLdsImage lds;                // the same tables, narrowed and packed for the kernels
 };
 
 // Returns 0 on success.  Pure host code, no HIP.
