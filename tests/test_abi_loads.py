@@ -143,3 +143,16 @@ def test_model_config_errors_without_gpu(tmp_path):
         load("Cmvn_Stats = stats.bin\n")            # keys are case-insensitive
     with pytest.raises(pk.PkError, match="Unable to find key 'right_context'"):
         load("cmvn_stats = stats.bin\nnnet = a\nprior = b\nleft_context = 5\n")
+
+
+def test_broadcast_entry_reports_misuse_without_gpu():
+    """pk_mi355_am_broadcast (the C-ABI form of the one collective): call-order and argument errors are
+    reported through the status channel before anything touches RCCL or the device."""
+    L = pk.lib()
+    am = L.pk_mi355_am_create()
+    try:
+        assert L.pk_mi355_am_broadcast(am, None, 0, None) != 0
+        assert b"not finalized" in L.pk_mi355_last_error()
+        assert L.pk_mi355_am_broadcast(None, None, 0, None) != 0
+    finally:
+        L.pk_mi355_am_destroy(am)
