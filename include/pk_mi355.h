@@ -237,7 +237,9 @@ int pk_mi355_batch_fetch(pk_mi355_batch_t *b, int utt, pk_decodable_t *out);
 /* All utterances at once: ONE device-to-host transfer into a page-locked arena the batch owns
  * (made on first use), and out[0..num_out) (num_out == pk_mi355_batch_num_utts) filled as
  * decodables whose log_prob VIEWS that arena -- same fields, same [T][num_pdfs] layout, usable
- * by Decoder::Decode like any other (decoder.cc:39).  pk_decodable_destroy on such a view
+ * by Decoder::Decode like any other (decoder.cc:39); their `am` field is an opaque tagged handle
+ * (that is how pk_decodable_destroy tells a view from a malloc'd matrix): copy such a struct whole
+ * and hand it to the pk_decodable_* functions only.  pk_decodable_destroy on such a view
  * frees nothing of the caller's and may happen at any time, also after pk_mi355_batch_destroy
  * (pocketkaldi.cc:247 destroys its decodable unconditionally): the arena is released when the
  * batch is gone AND the views of its last fetch_all have been destroyed.  The CONTENTS of the views

@@ -532,22 +532,15 @@ struct Arena {
   bool batch_alive;
 };
 std::vector<Arena> g_arenas;
-// Address ranges of arenas already released.  A view that outlived every count (one of an EARLIER
-// fetch_all, destroyed after a later fetch_all's views and the batch are gone) must still not reach
-// free(): its pointer was never malloc()'d.  If malloc() later hands out memory inside such a
-// range, that block is leaked by pk_decodable_destroy instead of freed -- the safe direction.
-std::vector<std::pair<const char *, const char *>> g_retired;
-void RetireRange(const Arena &a) {          // g_arena_mu held
-  if (g_retired.size() >= 256) g_retired.erase(g_retired.begin());
-  g_retired.emplace_back(a.lo, a.hi);
-}
+// Whether a decodable is a view is NOT guessed from its address: fetch_all tags the model handle it
+// stores in the view (bit 0 of pk_decodable_t.am, opaque to every caller; the four pk_decodable_*
+// functions mask it), so pk_decodable_destroy free()s exactly the matrices malloc() made.
+inline pk_mi355_am_t *TagView(pk_mi355_am_t *am) { return reinterpret_cast<pk_mi355_am_t *>(reinterpret_cast<uintptr_t>(am) | 1u); }
+inline bool IsView(const pk_mi355_am_t *am) { return (reinterpret_cast<uintptr_t>(am) & 1u) != 0; }
+inline pk_mi355_am_t *Untag(pk_mi355_am_t *am) { return reinterpret_cast<pk_mi355_am_t *>(reinterpret_cast<uintptr_t>(am) & ~uintptr_t(1)); }
 
 void RegisterArena(void *p, size_t bytes) {
   std::lock_guard<std::mutex> g(g_arena_mu);
-  const char *lo = static_cast<char *>(p), *hi = lo + bytes;
-  for (size_t i = 0; i < g_retired.size();)     // the address space is in use again
-    if (g_retired[i].first < hi && lo < g_retired[i].second) g_retired.erase(g_retired.begin() + i);
-    else ++i;
   g_arenas.push_back(Arena{static_cast<char *>(p), static_cast<char *>(p) + bytes, 0, true});
 }
 void SetArenaViews(const void *p, int views) {
@@ -563,33 +556,29 @@ void RetireArena(void *p) {
     for (size_t i = 0; i < g_arenas.size(); ++i)
       if (g_arenas[i].lo == p) {
         g_arenas[i].batch_alive = false;
-        if (g_arenas[i].live_views <= 0) { RetireRange(g_arenas[i]); g_arenas.erase(g_arenas.begin() + i); release = true; }
+        if (g_arenas[i].live_views <= 0) { g_arenas.erase(g_arenas.begin() + i); release = true; }
         break;
       }
   }
   if (release) hipHostFree(p);
 }
-// pk_decodable_destroy on `p`: true if p points into an arena (then nothing may be free()d).
-bool ReleaseArenaView(const void *p) {
-  if (!p) return false;
+// pk_decodable_destroy on a view whose matrix is `p`: one view fewer; the last one of a batch that is
+// gone releases the arena.  (A view of an EARLIER fetch_all, destroyed late, finds a count that is
+// not its own, or no arena at all: nothing to do -- it never owned anything.)
+void ReleaseArenaView(const void *p) {
+  if (!p) return;
   void *release = nullptr;
-  bool found = false;
   {
     std::lock_guard<std::mutex> g(g_arena_mu);
     for (size_t i = 0; i < g_arenas.size(); ++i) {
       Arena &a = g_arenas[i];
       if (static_cast<const char *>(p) < a.lo || static_cast<const char *>(p) >= a.hi) continue;
-      found = true;
       if (a.live_views > 0) --a.live_views;
-      if (!a.batch_alive && a.live_views == 0) { release = a.lo; RetireRange(a); g_arenas.erase(g_arenas.begin() + i); }
+      if (!a.batch_alive && a.live_views == 0) { release = a.lo; g_arenas.erase(g_arenas.begin() + i); }
       break;
     }
-    if (!found)
-      for (const auto &r : g_retired)
-        if (static_cast<const char *>(p) >= r.first && static_cast<const char *>(p) < r.second) { found = true; break; }
   }
   if (release) hipHostFree(release);
-  return found;
 }
 // One device-to-host result stream per device (pk_mi355_batch_fetch_all); lives for the process.
 hipStream_t ResultStream(int device) {
@@ -1111,8 +1100,9 @@ void pk_decodable_init(pk_decodable_t *self, pk_mi355_am_t *am, float prob_scale
 
 void pk_decodable_destroy(pk_decodable_t *self) {
   // matrix.cc:123-128 frees; a decodable handed out by pk_mi355_batch_fetch_all is a view of
-  // the batch's page-locked arena and owns nothing.
-  if (!ReleaseArenaView(self->log_prob.data)) free(self->log_prob.data);
+  // the batch's page-locked arena (tagged handle) and owns nothing.
+  if (IsView(self->am)) ReleaseArenaView(self->log_prob.data);
+  else free(self->log_prob.data);
   self->log_prob.data = nullptr;
   self->log_prob.nrow = 0;
   self->log_prob.ncol = 0;
@@ -1120,7 +1110,7 @@ void pk_decodable_destroy(pk_decodable_t *self) {
 }
 
 float pk_decodable_loglikelihood(pk_decodable_t *self, int frame, int trans_id) {
-  const int pdf = pk_mi355_am_transition_to_pdf(self->am, trans_id);
+  const int pdf = pk_mi355_am_transition_to_pdf(Untag(self->am), trans_id);
   return self->log_prob.data[(size_t)frame * self->log_prob.nrow + pdf];
 }
 
@@ -1473,7 +1463,7 @@ int pk_mi355_batch_fetch_all(pk_mi355_batch_t *b, pk_decodable_t *out, int num_o
   int views = 0;
   for (int u = 0; u < num_out; ++u) {
     const int T = b->h_T[u];
-    out[u].am = b->am;
+    out[u].am = TagView(b->am);
     out[u].log_prob.ncol = T;
     out[u].log_prob.nrow = T > 0 ? N : 0;
     out[u].log_prob.data = T > 0 ? b->h_ll + (size_t)b->h_pad_base[u] * N : nullptr;

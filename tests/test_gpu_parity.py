@@ -811,17 +811,17 @@ def test_view_destroyed_after_its_batch_is_safe():
         L_.pk_decodable_destroy(C.byref(stale[u]))      # drives the count of the second fetch_all to zero
     stale2 = (pk.pk_decodable_t * 3)()
     assert L_.pk_mi355_batch_fetch_all(bs3._h, stale2, 3, 1) == 0
-    keep = [(stale2[u].log_prob.ncol, stale2[u].log_prob.nrow, stale2[u].log_prob.data) for u in range(3)]
+    keep = [(stale2[u].log_prob.ncol, stale2[u].log_prob.nrow, stale2[u].log_prob.data, stale2[u].am) for u in range(3)]
     for u in range(3):
         L_.pk_decodable_destroy(C.byref(fresh[u]))
     L_.pk_mi355_batch_destroy(bs3._h)
     bs3._h = None
     late = (pk.pk_decodable_t * 3)()
     for u in range(3):                                   # bitwise copies of views whose arena is gone by now
-        late[u].log_prob.ncol, late[u].log_prob.nrow, late[u].log_prob.data = keep[u]
+        late[u].log_prob.ncol, late[u].log_prob.nrow, late[u].log_prob.data, late[u].am = keep[u]   # whole-struct copies
         L_.pk_decodable_destroy(C.byref(stale2[u]))
     for u in range(3):
-        L_.pk_decodable_destroy(C.byref(late[u]))        # pointers into a RETIRED arena: a no-op, not a free()
+        L_.pk_decodable_destroy(C.byref(late[u]))        # views (tagged handle) of an arena that is gone: a no-op, not a free()
     # Python mirror: closing the scorer while views are alive, views die later
     bs2 = pk.BatchScorer(am, synth.global_cmvn_stats(), 3, sum(len(w) for w in waves[:3]))
     bs2.set_waves(waves[:3])
