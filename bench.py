@@ -265,6 +265,30 @@ def other_configs(pk, synth, torch, steps):
         "gemm_tflops_algorithmic": alg, "gemm_tflops_mfma_issued": 3.0 * alg,
         "fp16_mfma_peak": FP16_MFMA_PEAK_TFLOPS, "frac_of_fp16_peak_issued": 3.0 * alg / FP16_MFMA_PEAK_TFLOPS,
         "stage_ms_per_step": {k: bw.timing()[k][0] for k in pk.KINDS}}
+    ll_x3 = bw.fetch(0).log_prob()
+    bw.close()
+    # the same workload with plain fp16 operands (one MFMA per product): the stated-tolerance ceiling
+    amp = pk.AcousticModel(layers, prior, L, R, precision="f16")
+    bw = pk.BatchScorer(amp, g, B, int(sum(ns)))
+    bw.set_waves_device(pcm.data_ptr(), ns, keep_alive=pcm)
+    bw.score(0.1, sync=True)
+    bw.enable_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        bw.score(0.1, sync=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    gm = bw.timing()["gemm"][0]
+    alg = amp.flops_per_frame() * bw.total_frames() / (gm * 1e-3) / 1e12
+    ll_p = bw.fetch(0).log_prob()
+    err = float(np.max(np.abs(ll_p.astype(np.float64) - ll_x3) / np.maximum(np.abs(ll_x3), 1.0)))
+    out["configs[4] wide model, plain f16 (1 MFMA per product; OUTSIDE the 1e-4 contract)"] = {
+        "frames_per_s": bw.total_frames() / dt, "ms_per_step": dt * 1e3,
+        "gemm_tflops_algorithmic": alg, "frac_of_fp16_peak_issued": alg / FP16_MFMA_PEAK_TFLOPS,
+        "measured_max_err_vs_f16x3": err,
+        "err_definition": "max |ll - ll_f16x3| / max(|ll_f16x3|, 1) over utterance 0 (f16x3 is within ~1e-6 of the fp32 chain)",
+        "stage_ms_per_step": {k: bw.timing()[k][0] for k in pk.KINDS}}
     bw.close()
     return out
 
@@ -277,8 +301,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=10.0, help="audio per utterance")
     ap.add_argument("--model", default="S", choices=["S", "W", "tiny"])
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
-                    help="f32: bit-exact fp32 MFMA (default); f16x3: split-fp16 on the fp16 matrix cores")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3", "f16"],
+                    help="f32: bit-exact fp32 MFMA (default); f16x3: split-fp16 on the fp16 matrix cores (inside the 1e-4 "
+                         "contract); f16: plain fp16 operands, one MFMA per product, OUTSIDE the contract (~1e-3)")
     ap.add_argument("--softmax", default="stable", choices=["stable", "reference"],
                     help="stable: overflow-safe log-softmax tail (default); reference: the reference's softmax "
                          "operations one by one -- with f32 the whole path is then bit-identical to the CPU path")
@@ -409,7 +434,8 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "f16x3 (fp16 hi+lo operands, 3 MFMA per product, f32 accumulate)",
+            "dtype": {"f32": "f32", "f16x3": "f16x3 (fp16 hi+lo operands, 3 MFMA per product, f32 accumulate)",
+                      "f16": "f16 (plain fp16 operands, f32 accumulate; outside the 1e-4 contract)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "%d utterances x %.0f s 16 kHz per GPU (BASELINE configs[2]; x8 = configs[3]), "
                                    "440 -> %d x %d ReLU -> %d softmax, fbank+CMVN+nnet, PCM resident in HBM"

@@ -275,7 +275,7 @@ class AcousticModel:
     """
     _KIND = {"relu": RELU, "normalize": NORMALIZE, "softmax": SOFTMAX}
 
-    PRECISIONS = {"f32": 0, "f16x3": 1}
+    PRECISIONS = {"f32": 0, "f16x3": 1, "f16": 2}
 
     def __init__(self, layers=None, prior=None, left_context=0, right_context=0, tid2pdf=None,
                  num_pdfs=None, precision="f32"):

@@ -48,6 +48,8 @@ int Fail(int code, const char *fmt, ...) {
   } while (0)
 
 inline int64_t RoundUp(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+// the two precisions that run on the fp16 matrix cores share layouts and code paths
+inline bool IsF16(int precision) { return precision == PK_MI355_PRECISION_F16X3 || precision == PK_MI355_PRECISION_F16; }
 
 int UseDevice(int device) {
   int n = 0;
@@ -206,7 +208,7 @@ struct ExecBufs {
 
 int AllocExec(const pk_mi355_am *am, int64_t rows_cap, ExecBufs *e) {
   e->rows_cap = rows_cap;
-  if (am->precision == PK_MI355_PRECISION_F16X3) {
+  if (IsF16(am->precision)) {
     const size_t act = sizeof(_Float16) * 2 * (size_t)am->max_dim_pad * rows_cap;
     const size_t xin = sizeof(_Float16) * 2 * (size_t)RoundUp(am->input_dim, kBKF16) * (rows_cap + 16);
     for (int i = 0; i < 2; ++i) {
@@ -409,6 +411,7 @@ int RunLayersF16(const pk_mi355_am *am, const ExecBufs &e, const _Float16 *x, in
     g.ldo = last ? D.Npad : 2 * D.Npad;
     g.tiles_m = rows_pad / kTileF16;
     g.tiles_n = D.Npad / kTileF16;
+    g.terms = am->precision == PK_MI355_PRECISION_F16 ? 1 : 3;
     {
       Scoped t(timer, PK_MI355_K_GEMM, stream);
       LaunchGemmF16(g, stream);
@@ -473,7 +476,7 @@ int EnsureWorkspace(pk_mi355_am *am, int64_t frames, int width) {
     w->yt_ld = need_ld;
     HIP_TRY(hipMalloc(&w->d_yt, sizeof(float) * w->yt_ld * am->feat_dim));
     HIP_TRY(hipMemset(w->d_yt, 0, sizeof(float) * w->yt_ld * am->feat_dim));
-    if (am->precision == PK_MI355_PRECISION_F16X3) {
+    if (IsF16(am->precision)) {
       hipFree(w->d_y2);
       HIP_TRY(hipMalloc(&w->d_y2, sizeof(_Float16) * 2 * w->yt_ld * am->feat_dim));
     }
@@ -655,7 +658,7 @@ int pk_mi355_am_add_layer(pk_mi355_am_t *am, int layer_type) {
 
 int pk_mi355_am_set_precision(pk_mi355_am_t *am, int precision) {
   if (!am || am->finalized) return Fail(PK_MI355_E_STATE, "set the precision before finalizing the model");
-  if (precision != PK_MI355_PRECISION_F32 && precision != PK_MI355_PRECISION_F16X3)
+  if (precision != PK_MI355_PRECISION_F32 && precision != PK_MI355_PRECISION_F16X3 && precision != PK_MI355_PRECISION_F16)
     return Fail(PK_MI355_E_INVALID, "unknown precision %d", precision);
   am->precision = precision;
   return 0;
@@ -683,7 +686,7 @@ int pk_mi355_am_finalize(pk_mi355_am_t *am, const float *prior, int num_pdfs, in
   if (rc) return rc;
 
   // dimension chain
-  const bool f16 = am->precision == PK_MI355_PRECISION_F16X3;
+  const bool f16 = IsF16(am->precision);
   if (f16) {
     // the split-fp16 path covers the BASELINE model family: (Linear [ReLU])+ [Softmax]
     const int nl = (int)am->layers.size();
@@ -695,7 +698,7 @@ int pk_mi355_am_finalize(pk_mi355_am_t *am, const float *prior, int num_pdfs, in
       else if (t != PK_NNET_LINEAR_LAYER) ok = false;
     }
     if (ok && am->layers.back().type == PK_NNET_RELU_LAYER && nl >= 2) ok = true;
-    if (!ok) return Fail(PK_MI355_E_INVALID, "f16x3 precision supports (Linear [ReLU])+ [Softmax] networks only");
+    if (!ok) return Fail(PK_MI355_E_INVALID, "f16x3 / f16 precision supports (Linear [ReLU])+ [Softmax] networks only");
   }
   int first_in = 0, dim = 0;
   am->lin.clear();
@@ -1032,7 +1035,7 @@ int pk_mi355_nnet_propagate(pk_mi355_am_t *am, const pk_matrix_t *in, pk_matrix_
   for (int64_t r0 = 0; r0 < T; r0 += kSingleChunk) {
     const int rows = (int)std::min<int64_t>(kSingleChunk, T - r0);
     ExecResult res;
-    if (am->precision == PK_MI355_PRECISION_F16X3) {
+    if (IsF16(am->precision)) {
       const int kp = (int)RoundUp(D, kBKF16);
       LaunchSplitF16(w->d_feats + r0 * D, D, 1, rows, D, kp, w->exec.xin, 2 * kp, w->stream);
       rc = RunLayersF16(am, w->exec, w->exec.xin, 2 * kp, rows, false, 1.0f, nullptr, 0, w->stream, nullptr, &res);
@@ -1065,11 +1068,11 @@ void pk_decodable_init(pk_decodable_t *self, pk_mi355_am_t *am, float prob_scale
   if (UseDevice(am->device)) return;
   const int T = feats->ncol, D = feats->nrow, N = am->num_pdfs;
   if (T <= 0) return;
-  const bool f16 = am->precision == PK_MI355_PRECISION_F16X3;
+  const bool f16 = IsF16(am->precision);
   if (f16 && D % 8 != 0) {
     // the interleaved (hi, lo) row of a frame is made of whole 8-k chunks: the spliced view
     // (row stride 2 D halves, gemm_f16.hip) exists only for such D
-    Fail(PK_MI355_E_INVALID, "f16x3 precision needs a feature dimension that is a multiple of 8 (got %d)", D);
+    Fail(PK_MI355_E_INVALID, "f16x3 / f16 precision needs a feature dimension that is a multiple of 8 (got %d)", D);
     return;
   }
   std::lock_guard<std::mutex> lock(am->mu);
@@ -1259,7 +1262,7 @@ pk_mi355_batch_t *pk_mi355_batch_create(pk_mi355_am_t *am, const float *global_s
   if (ok) b->d_raw = b->d_raw_alloc + kCmvnRawLead;
   chk(hipMalloc(&b->d_yt, sizeof(float) * b->ldy * kNumBins));
   if (ok) chk(hipMemset(b->d_yt, 0, sizeof(float) * b->ldy * kNumBins));
-  if (am->precision == PK_MI355_PRECISION_F16X3) {
+  if (IsF16(am->precision)) {
     chk(hipMalloc(&b->d_y2, sizeof(_Float16) * 2 * b->ldy * kNumBins));
   }
   chk(hipMalloc(&b->d_ll, sizeof(float) * b->max_cols * am->num_pdfs));
@@ -1363,7 +1366,7 @@ int pk_mi355_batch_score(pk_mi355_batch_t *b, float prob_scale, int sync) {
   // [pad_base, pad_base + T)) is its frame r - pad_base.  The few rows that
   // straddle two utterances are computed and ignored.
   const int N = am->num_pdfs;
-  const bool f16 = am->precision == PK_MI355_PRECISION_F16X3;
+  const bool f16 = IsF16(am->precision);
   if (f16) {
     Scoped t(tm, PK_MI355_K_OTHER, b->stream);
     LaunchSplitF16(b->d_yt, 1, b->ldy, (int)b->ldy, kNumBins, kNumBins, b->d_y2, 2 * kNumBins, b->stream);

@@ -89,7 +89,10 @@ __device__ __forceinline__ SplitOut Split(float v) {
 #define PK_STAMP(i) do { } while (0)
 #endif
 
-template <bool RELU, bool LAST>
+// TERMS = 3: the split-fp16 arithmetic above.  TERMS = 1 (PK_MI355_PRECISION_F16): the hi halves only --
+// plain fp16 operands, one MFMA per product; same layouts (the lo halves travel unused), so the mode
+// is bound by the L2 -> LDS operand stream rather than by the matrix pipes.
+template <bool RELU, bool LAST, int TERMS>
 __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the ring: 4 x 32 KiB
 #ifdef PK_F16_STAMPS
@@ -184,13 +187,13 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
   f16x8 bh[2][2], bl[2][2];    // B fragments of the current / next step: [parity][y]
   auto read_a = [&](const unsigned char *base, int x, f16x8 &h, f16x8 &l) {
     h = *reinterpret_cast<const f16x8 *>(base + aoff_h[x]);
-    l = *reinterpret_cast<const f16x8 *>(base + aoff_l[x]);
+    if (TERMS == 3) l = *reinterpret_cast<const f16x8 *>(base + aoff_l[x]);
   };
   auto read_b = [&](const unsigned char *base, int par) {
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
       bh[par][y] = *reinterpret_cast<const f16x8 *>(base + boff_h[y]);
-      bl[par][y] = *reinterpret_cast<const f16x8 *>(base + boff_l[y]);
+      if (TERMS == 3) bl[par][y] = *reinterpret_cast<const f16x8 *>(base + boff_l[y]);
     }
   };
   read_b(smem, 0);
@@ -203,8 +206,8 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
 #endif
   auto mfma3 = [&](int x, int y, int cur, int par, int which) {
     // the three products of one (x, y) tile and k16 step: hi lo, lo hi, hi hi -- in this order
-    if (which == 0) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[par][y], acc[x][y], 0, 0, 0);
-    if (which == 1) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[par][y], acc[x][y], 0, 0, 0);
+    if (TERMS == 3 && which == 0) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[par][y], acc[x][y], 0, 0, 0);
+    if (TERMS == 3 && which == 1) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[par][y], acc[x][y], 0, 0, 0);
     if (which == 2) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[par][y], acc[x][y], 0, 0, 0);
   };
   // (Measured and dropped: waves 4-7 issuing their pieces in the second and third group instead,
@@ -367,23 +370,21 @@ void LaunchGemmF16(const GemmF16Args &a, hipStream_t stream) {
   const size_t lds = kRingF16 * kHalfSlabBytes;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmF16Kernel<true, false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmF16Kernel<false, false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmF16Kernel<true, true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmF16Kernel<false, true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#define PK_SET_LDS(R, L, T) hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmF16Kernel<R, L, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+    PK_SET_LDS(true, false, 3); PK_SET_LDS(false, false, 3); PK_SET_LDS(true, true, 3); PK_SET_LDS(false, true, 3);
+    PK_SET_LDS(true, false, 1); PK_SET_LDS(false, false, 1); PK_SET_LDS(true, true, 1); PK_SET_LDS(false, true, 1);
+#undef PK_SET_LDS
     attr_set = true;
   }
-  if (a.out_f32) {
-    if (a.relu) hipLaunchKernelGGL((GemmF16Kernel<true, true>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((GemmF16Kernel<false, true>), grid, block, lds, stream, a);
+#define PK_LAUNCH(R, L, T) hipLaunchKernelGGL((GemmF16Kernel<R, L, T>), grid, block, lds, stream, a)
+  if (a.terms == 1) {
+    if (a.out_f32) { if (a.relu) PK_LAUNCH(true, true, 1); else PK_LAUNCH(false, true, 1); }
+    else { if (a.relu) PK_LAUNCH(true, false, 1); else PK_LAUNCH(false, false, 1); }
   } else {
-    if (a.relu) hipLaunchKernelGGL((GemmF16Kernel<true, false>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((GemmF16Kernel<false, false>), grid, block, lds, stream, a);
+    if (a.out_f32) { if (a.relu) PK_LAUNCH(true, true, 3); else PK_LAUNCH(false, true, 3); }
+    else { if (a.relu) PK_LAUNCH(true, false, 3); else PK_LAUNCH(false, false, 3); }
   }
+#undef PK_LAUNCH
 }
 
 void LaunchSplitF16(const float *in, int64_t stride_r, int64_t stride_c, int rows, int cols,

@@ -100,6 +100,7 @@ struct GemmF16Args {
   _Float16 *out;
   int64_t ldo;           // floats (out_f32) or halves (out)
   int tiles_m, tiles_n;  // 256 x 256 tiles
+  int terms = 3;         // 3: hi hi + hi lo + lo hi (f16x3); 1: hi hi only (plain fp16 operands)
 };
 void LaunchGemmF16(const GemmF16Args &a, hipStream_t stream);
 

@@ -880,3 +880,30 @@ def test_more_utterances_than_cus():
         c = O.cmvn(g, f)
         assert bits_equal(bs.fetch_fbank(u), f) and bits_equal(bs.fetch_cmvn(u), c)
         assert bits_equal(bs.fetch(u).log_prob(), nn.am_compute(c, prior, L, R, 0.1))
+
+
+# ------------------------------------------------------------------ plain fp16 mode (PK_MI355_PRECISION_F16)
+# ONE fp16 MFMA per product on the hi halves only: the throughput ceiling of the fp16 matrix cores at a
+# STATED tolerance of its own -- outside the path's 1e-4 contract, so the
+# test states the looser bar and prints what was measured.
+
+def test_plain_f16_mode_states_its_own_tolerance(capsys):
+    layers, prior, L, R = synth.model("S")
+    wave = synth.utterance(0, seconds=3.0)
+    g = synth.global_cmvn_stats()
+    ref = O.Nnet(layers).am_compute(O.cmvn(g, O.Fbank().compute(wave)), prior, L, R, 0.1)
+    errs, agree = {}, {}
+    for prec in ("f16x3", "f16"):
+        am = pk.AcousticModel(layers, prior, L, R, precision=prec)
+        bs = pk.BatchScorer(am, g, 1, wave.shape[0])
+        bs.set_waves([wave])
+        bs.score(0.1)
+        got = bs.fetch(0).log_prob()
+        errs[prec] = float(np.max(np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1.0)))
+        agree[prec] = float(np.mean(np.argmax(got, axis=1) == np.argmax(ref, axis=1)))
+    with capsys.disabled():
+        print("\n  max |err| / max(|ref|, 1) on log-likelihoods, model S: f16x3 %.2e, plain f16 %.2e; "
+              "top-1 pdf agreement %.4f / %.4f" % (errs["f16x3"], errs["f16"], agree["f16x3"], agree["f16"]))
+    assert errs["f16x3"] < 1e-4                     # the contract
+    assert 1e-5 < errs["f16"] < 2e-2                # plain fp16: its own, looser, stated bar (measured ~1e-3)
+    assert agree["f16"] > 0.97                      # the frame-level decision is barely affected
