@@ -52,7 +52,7 @@ def test_pk_load_reads_the_reference_written_model(precision):
     the model built in memory from the text, bit for bit; and == the oracle on the same features."""
     layers, prior, L, R, tid2pdf, cmvn41 = load_text_model()
     if precision == "f16x3":        # the model has a Normalize layer: f16x3 covers (Linear [ReLU])+ [Softmax] only
-        with pytest.raises(pk.PkError, match="f16x3 precision supports"):
+        with pytest.raises(pk.PkError, match="precision supports"):
             pk.AcousticModel.load(os.path.join(DIR, "refmodel.conf"), precision=precision)
         return
     am_file, stats = pk.AcousticModel.load(os.path.join(DIR, "refmodel.conf"), precision=precision)
