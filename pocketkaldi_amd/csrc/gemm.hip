@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
     const uint32_t voff = (lane % G::kLanesPerRow) * 16 + ((second != (off1 < off0)) ? dist : 0u);
     DmaScalarBase(smem + (slot_to * 2 + 1) * kSlab + row * kBT, reinterpret_cast<const char *>(qg + lo), voff);
     sd[j] += kBK;
-    if (sd[j] >= a.splice_dim) { sd[j] -= a.splice_dim; ++sc[j]; }
+    while (sd[j] >= a.splice_dim) { sd[j] -= a.splice_dim; ++sc[j]; }   // (once, unless the dimension is below 16)
   };
 
   // The bias values are fetched in one batch (a per-element runtime select makes hipcc branch

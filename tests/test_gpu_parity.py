@@ -907,3 +907,22 @@ def test_plain_f16_mode_states_its_own_tolerance(capsys):
     assert errs["f16x3"] < 1e-4                     # the contract
     assert 1e-5 < errs["f16"] < 2e-2                # plain fp16: its own, looser, stated bar (measured ~1e-3)
     assert agree["f16"] > 0.97                      # the frame-level decision is barely affected
+
+
+@pytest.mark.parametrize("D,L,R", [(40, 5, 5), (8, 3, 2), (6, 4, 4), (7, 2, 1)])
+def test_spliced_first_layer_big_tiles_any_feature_dimension(D, L, R):
+    """The 128 x 128-tile kernel's spliced operand (am.cc:65-88 as an address function) for even and odd
+    feature dimensions; dimensions below the 16-row k-slab wrap more than once per slab (round 1 wrapped
+    at most once: wrong addresses for feature dimensions below 16 in the big-tile variant).  4096-row passes x 1536 outputs = 384 tiles of 128: the big-tile variant."""
+    rng = np.random.default_rng(D * 100 + L)
+    K, N, T = D * (L + R + 1), 1536, 9000
+    W = (rng.standard_normal((N, K)) * np.sqrt(2.0 / K)).astype(np.float32)
+    layers = [("linear", W, (rng.standard_normal(N) * 0.1).astype(np.float32)), ("relu",),
+              ("linear", (rng.standard_normal((30, N)) * 0.1).astype(np.float32), np.zeros(30, np.float32)), ("softmax",)]
+    prior = np.full(30, 1 / 30, np.float32)
+    feats = rng.standard_normal((T, D)).astype(np.float32)
+    am = pk.AcousticModel(layers, prior, L, R).set_softmax("reference")
+    got = pk.Decodable(am, 0.1, feats).log_prob()
+    rows = np.r_[0:300, T // 2:T // 2 + 300, T - 300:T]
+    ref = O.Nnet(layers).am_compute(feats, prior, L, R, 0.1)
+    assert bits_equal(got[rows], ref[rows]) and bits_equal(got, ref)
