@@ -926,3 +926,78 @@ def test_spliced_first_layer_big_tiles_any_feature_dimension(D, L, R):
     rows = np.r_[0:300, T // 2:T // 2 + 300, T - 300:T]
     ref = O.Nnet(layers).am_compute(feats, prior, L, R, 0.1)
     assert bits_equal(got[rows], ref[rows]) and bits_equal(got, ref)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_layer_stacks_bit_exact(seed):
+    """Random layer stacks through Nnet::Propagate (nnet.cc:149-163): random widths (not multiples of
+    anything), depths, ReLU / Normalize in any position, optional softmax (reference arithmetic), random
+    frame counts -- every output bit equal to the oracle's."""
+    rng = np.random.default_rng(4242 + seed)
+    depth = int(rng.integers(1, 5))
+    dims = [int(rng.integers(1, 700))] + [int(rng.integers(1, 500)) for _ in range(depth)]
+    layers = []
+    for i in range(depth):
+        W = (rng.standard_normal((dims[i + 1], dims[i])) * np.sqrt(2.0 / dims[i])).astype(np.float32)
+        layers.append(("linear", W, (rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32)))
+        if rng.random() < 0.7:
+            layers.append(("relu",))
+        if rng.random() < 0.3:
+            layers.append(("normalize",))
+    if rng.random() < 0.5:
+        layers.append(("softmax",))
+    T = int(rng.choice([1, 2, 63, 64, 65, 127, 129, 300, 1100]))
+    x = rng.standard_normal((T, dims[0])).astype(np.float32)
+    am = pk.AcousticModel(layers, num_pdfs=dims[-1]).set_softmax("reference")
+    got, ref = am.propagate(x), O.Nnet(layers).propagate(x)
+    assert _bits_equal_nan(got, ref), "layers %s T %d dims %s" % ([l[0] for l in layers], T, dims)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_decodable_contexts_and_dimensions(seed):
+    """pk_decodable_init (decodable.cc:8-17) with random feature dimension, left / right context, widths
+    and frame counts (one frame up to several 4096-frame passes): bit-identical to AcousticModel::Compute
+    in the oracle with the reference softmax, and the lookup semantics of decodable.cc:24-36."""
+    rng = np.random.default_rng(777 + seed)
+    D = int(rng.integers(1, 49))
+    L, R = int(rng.integers(0, 7)), int(rng.integers(0, 7))
+    H, N = int(rng.integers(1, 300)), int(rng.integers(2, 400))
+    K = D * (L + R + 1)
+    layers = [("linear", (rng.standard_normal((H, K)) * np.sqrt(2.0 / K)).astype(np.float32),
+               (rng.standard_normal(H) * 0.1).astype(np.float32)), ("relu",),
+              ("linear", (rng.standard_normal((N, H)) * np.sqrt(2.0 / H)).astype(np.float32),
+               (rng.standard_normal(N) * 0.1).astype(np.float32)), ("softmax",)]
+    prior = rng.uniform(0.5, 1.5, N)
+    prior = (prior / prior.sum()).astype(np.float32)
+    T = int(rng.choice([1, 2, 5, 64, 500, 4096, 4097, 9000]))
+    feats = rng.standard_normal((T, D)).astype(np.float32)
+    tid2pdf = np.concatenate([[0], rng.integers(0, N, 40)]).astype(np.int32)
+    am = pk.AcousticModel(layers, prior, L, R, tid2pdf).set_softmax("reference")
+    d = pk.Decodable(am, 0.1, feats)
+    ref = O.Nnet(layers).am_compute(feats, prior, L, R, 0.1)
+    assert bits_equal(d.log_prob(), ref), "D %d L %d R %d H %d N %d T %d" % (D, L, R, H, N, T)
+    assert d.is_last_frame(T - 1) and not d.is_last_frame(T - 2 if T > 1 else -1)
+    assert d.loglikelihood(T - 1, 7) == ref[T - 1, tid2pdf[7]]
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_f16x3_decodable_within_contract(seed):
+    """f16x3 through pk_decodable_init with random (multiple-of-8) feature dimensions, contexts, widths,
+    depths and frame counts: inside the 1e-4 contract everywhere, measured error an order below."""
+    rng = np.random.default_rng(999 + seed)
+    D = 8 * int(rng.integers(1, 7))
+    L, R = int(rng.integers(0, 6)), int(rng.integers(0, 6))
+    dims = [D * (L + R + 1)] + [int(rng.integers(8, 600)) for _ in range(int(rng.integers(1, 4)))] + [int(rng.integers(2, 700))]
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(("linear", (rng.standard_normal((dims[i + 1], dims[i])) * np.sqrt(2.0 / dims[i])).astype(np.float32),
+                       (rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32)))
+        layers.append(("relu",) if i < len(dims) - 2 else ("softmax",))
+    prior = rng.uniform(0.5, 1.5, dims[-1])
+    prior = (prior / prior.sum()).astype(np.float32)
+    T = int(rng.choice([1, 3, 255, 256, 257, 1000, 4500]))
+    feats = rng.standard_normal((T, D)).astype(np.float32)
+    got = pk.Decodable(pk.AcousticModel(layers, prior, L, R, precision="f16x3"), 0.1, feats).log_prob()
+    ref = O.Nnet(layers).am_compute(feats, prior, L, R, 0.1)
+    assert_loglik_close(got, ref)
+    assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)) < 2e-5, "dims %s L %d R %d T %d" % (dims, L, R, T)
