@@ -20,6 +20,13 @@ import pocketkaldi_amd as pk
 from pocketkaldi_amd import synth
 from oracle import oracle as O
 
+
+def fuzz_seeds(n):
+    """Seeds of a fuzz test: 0..n-1 by default; a soak run on the GPU box widens and moves the range
+    (PK_FUZZ_SEEDS=count, PK_FUZZ_BASE=first seed; tools/soak.sh)."""
+    base = int(os.environ.get("PK_FUZZ_BASE", "0"))
+    return range(base, base + int(os.environ.get("PK_FUZZ_SEEDS", n)))
+
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 KNOWN = json.load(open(os.path.join(G, "ref_known_answers.json")))
 
@@ -668,7 +675,7 @@ def test_reference_softmax_whole_path_is_bit_identical_to_the_reference():
 
 
 # ------------------------------------------------------------------ seeded fuzz
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", fuzz_seeds(6))
 def test_fuzz_ragged_batches_every_stage(seed, monkeypatch):
     """Random ragged batches (lengths around the frame, CMVN-tile, window and chunk boundaries),
     random chunk size and lane count, int16 or float ingestion: features bit-exact per utterance,
@@ -928,7 +935,7 @@ def test_spliced_first_layer_big_tiles_any_feature_dimension(D, L, R):
     assert bits_equal(got[rows], ref[rows]) and bits_equal(got, ref)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", fuzz_seeds(24))
 def test_fuzz_layer_stacks_bit_exact(seed):
     """Random layer stacks through Nnet::Propagate (nnet.cc:149-163): random widths (not multiples of
     anything), depths, ReLU / Normalize in any position, optional softmax (reference arithmetic), random
@@ -953,7 +960,7 @@ def test_fuzz_layer_stacks_bit_exact(seed):
     assert _bits_equal_nan(got, ref), "layers %s T %d dims %s" % ([l[0] for l in layers], T, dims)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", fuzz_seeds(16))
 def test_fuzz_decodable_contexts_and_dimensions(seed):
     """pk_decodable_init (decodable.cc:8-17) with random feature dimension, left / right context, widths
     and frame counts (one frame up to several 4096-frame passes): bit-identical to AcousticModel::Compute
@@ -980,7 +987,7 @@ def test_fuzz_decodable_contexts_and_dimensions(seed):
     assert d.loglikelihood(T - 1, 7) == ref[T - 1, tid2pdf[7]]
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", fuzz_seeds(10))
 def test_fuzz_f16x3_decodable_within_contract(seed):
     """f16x3 through pk_decodable_init with random (multiple-of-8) feature dimensions, contexts, widths,
     depths and frame counts: inside the 1e-4 contract everywhere, measured error an order below."""
@@ -1001,3 +1008,65 @@ def test_fuzz_f16x3_decodable_within_contract(seed):
     ref = O.Nnet(layers).am_compute(feats, prior, L, R, 0.1)
     assert_loglik_close(got, ref)
     assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)) < 2e-5, "dims %s L %d R %d T %d" % (dims, L, R, T)
+
+
+def _random_net(rng, dims, normalize_p=0.0):
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(("linear", (rng.standard_normal((dims[i + 1], dims[i])) * np.sqrt(2.0 / dims[i])).astype(np.float32),
+                       (rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32)))
+        if i < len(dims) - 2:
+            layers.append(("relu",))
+            if rng.random() < normalize_p:
+                layers.append(("normalize",))
+        else:
+            layers.append(("softmax",))
+    prior = rng.uniform(0.5, 1.5, dims[-1])
+    return layers, (prior / prior.sum()).astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", fuzz_seeds(6))
+def test_fuzz_big_tile_decodable(seed):
+    """The 128 x 128-tile GEMM variants (gemm.hip LaunchGeo<2>: spliced first layer, accumulation over
+    several 512-chunks, swapped roles for the last layer) through pk_decodable_init: widths 1400-2300 that
+    are multiples of nothing, any feature dimension and context, 4096-frame passes -- bit-identical to
+    the oracle's AcousticModel::Compute with the reference softmax."""
+    rng = np.random.default_rng(31337 + seed)
+    D = int(rng.integers(1, 49))
+    L, R = int(rng.integers(0, 7)), int(rng.integers(0, 7))
+    hidden = [int(rng.integers(1537, 2300)) for _ in range(int(rng.integers(1, 3)))]
+    dims = [D * (L + R + 1)] + hidden + [int(rng.integers(1410, 3100))]
+    layers, prior = _random_net(rng, dims, normalize_p=0.25)
+    T = int(rng.choice([4096, 4100, 6000, 8200]))
+    feats = rng.standard_normal((T, D)).astype(np.float32)
+    am = pk.AcousticModel(layers, prior, L, R).set_softmax("reference")
+    got = pk.Decodable(am, 0.1, feats).log_prob()
+    ref = O.Nnet(layers).am_compute(feats, prior, L, R, 0.1)
+    assert bits_equal(got, ref), "dims %s L %d R %d T %d layers %s" % (dims, L, R, T, [l[0] for l in layers])
+
+
+@pytest.mark.parametrize("seed", fuzz_seeds(4))
+def test_fuzz_batches_wide_model_both_precisions(seed, monkeypatch):
+    """Ragged batches through the batched scorer with a model wide enough for the big-tile kernels of
+    both precisions, random layer-stack chunk: f32 bit-identical with the reference softmax and within
+    the contract with the default tail; f16x3 within the contract."""
+    rng = np.random.default_rng(90210 + seed)
+    dims = [440] + [int(rng.integers(520, 1300)) for _ in range(int(rng.integers(2, 4)))] + [int(rng.integers(900, 2100))]
+    layers, prior = _random_net(rng, dims)
+    g = synth.global_cmvn_stats()
+    lens = [int(rng.integers(400, 64000)) for _ in range(int(rng.integers(12, 30)))]
+    waves = [synth.utterance(9000 + 64 * seed + i, seconds=4.0)[:n] for i, n in enumerate(lens)]
+    monkeypatch.setenv("PK_MI355_CHUNK", str(int(rng.choice([1024, 4096, 8192, 131072]))))
+    nn, fb = O.Nnet(layers), O.Fbank()
+    refs = [nn.am_compute(O.cmvn(g, fb.compute(w)), prior, 5, 5, 0.1) for w in waves]
+    for prec, mode in (("f32", "reference"), ("f32", "stable"), ("f16x3", "stable")):
+        am = pk.AcousticModel(layers, prior, 5, 5, precision=prec).set_softmax(mode)
+        bs = pk.BatchScorer(am, g, len(waves), sum(lens))
+        bs.set_waves_i16([w.astype(np.int16) for w in waves])
+        bs.score(0.1)
+        for u, ll in enumerate(refs):
+            got = bs.fetch(u).log_prob()
+            if mode == "reference":
+                assert bits_equal(got, ll), "dims %s utt %d" % (dims, u)
+            else:
+                assert_loglik_close(got, ll)
