@@ -40,9 +40,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // split arrays; the arithmetic is the same), and every butterfly moves whole complex
 // values, so each LDS access is one 8-byte word.
 template <int LOGM>
-__device__ __forceinline__ void LButterfly(f32x2 *z, int base, int n, const float *__restrict__ tw) {
-  constexpr int m = 1 << LOGM, m2 = m / 2, m4 = m / 4, m8 = m / 8;
-  const int i0 = base + n, i1 = i0 + m4, i2 = i0 + m2, i3 = i2 + m4;
+__device__ __forceinline__ void LButterfly(f32x2 *z, unsigned pts, int n, const float (&tw)[6]) {
+  constexpr int m = 1 << LOGM, m8 = m / 8;
+  // the LDS slots of points n, n + m/4, n + m/2, n + 3m/4 of the block (FftLane::pts); unpacked per
+  // frame (kept unpacked across the frame loop they cost 40 registers and a wave per SIMD)
+  asm volatile("" : "+v"(pts));
+  const int i0 = pts & 255, i1 = (pts >> 8) & 255, i2 = (pts >> 16) & 255, i3 = pts >> 24;
   const f32x2 z0 = z[i0], z1 = z[i1], z2 = z[i2], z3 = z[i3];
 
   float ar = z0[0] + z2[0], br = z0[0] - z2[0];
@@ -67,8 +70,8 @@ __device__ __forceinline__ void LButterfly(f32x2 *z, int base, int n, const floa
       q2 = -sq * (r2 + q2);
       r2 = t2;
     } else if (LOGM >= 4) {
-      const float cn = tw[0 * m4 + n], spcn = tw[1 * m4 + n], smcn = tw[2 * m4 + n];
-      const float c3n = tw[3 * m4 + n], spc3n = tw[4 * m4 + n], smc3n = tw[5 * m4 + n];
+      const float cn = tw[0], spcn = tw[1], smcn = tw[2];
+      const float c3n = tw[3], spc3n = tw[4], smc3n = tw[5];
       float t2 = cn * (r1 + q1);
       float t1 = spcn * r1 + t2;
       r1 = smcn * q1 + t2;
@@ -105,17 +108,79 @@ __device__ __forceinline__ void WaveSync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int LOGM>
-__device__ __forceinline__ void FftPass(f32x2 *z, int lane, const LdsTables &tab) {
-  constexpr int pass = kLogCplx - LOGM;
-  constexpr int q = (1 << LOGM) / 4;        // butterflies per block
-  const int first = tab.pass_start[pass];
-  const int nblk = tab.pass_start[pass + 1] - first;
-  const int b = lane / q, n = lane % q;     // q is a power of two
-  if (b < nblk) {
-    const float *tw = LOGM >= 4 ? tab.tw + tab.tw_off[LOGM] : nullptr;
-    LButterfly<LOGM>(z, tab.blk_off[first + b], n, tw);
+// What a lane needs from the tables for EVERY frame it transforms -- where its butterfly of each
+// pass starts, that butterfly's six coefficients, its two-point blocks, its two bins of the real
+// post-pass -- read from the LDS tables once, kept in registers.  (The kernel is LDS-bound:
+// SQ_ACTIVE_INST_LDS fills the CU's LDS pipe, profiles/r02_S_pmc_valu.json; these reads were
+// 60 of a frame's 154 LDS instructions.)
+// LDS slot of complex point i.  With the plain layout the late passes (many small blocks, one lane
+// each), the two-point blocks and above all the bit-reversed reads of the post-pass put 4 to 16 lanes
+// of every 16 on the same banks: SQ_LDS_BANK_CONFLICT was 42 % of the kernel's CU-busy cycles.  The
+// low four bits of the index are XOR-ed with a GF(2)-linear image of the high four; the map was
+// chosen by enumerating all 65 536 of them against the kernel's exact access lists
+// (tools/fft_lds_swizzle.py): 560 -> 60 conflict cycles per frame.
+__device__ __forceinline__ int FftSlot(int i) {
+  const int h = i >> 4;
+  const int x = ((h & 1) ? 10 : 0) ^ ((h & 2) ? 5 : 0) ^ ((h & 4) ? 8 : 0) ^ ((h & 8) ? 4 : 0);
+  return i ^ x;
+}
+
+struct FftLane {
+  unsigned pts[kNumPasses - 1];      // passes LOGM = 8..2: the slots of this lane's four points, a byte each
+  unsigned active;                   // bit p: this lane has a butterfly in pass p; bits 8, 9: a two-point block
+  float tw[5][6];                    // LOGM = 8..4: cn, -(s+c), s-c, c3n, -(s3+c3), s3-c3 (srfft.cc:45-93)
+  unsigned two;                      // slots of the two-point blocks (srfft.cc:140-150): a0, a0 + 1, a1, a1 + 1
+  unsigned post;                     // post-pass: slots of bins k = 1 + lane + 64 r and 256 - k, bit-reversed
+  float kre[2], kim[2];              // exp(-2 pi i k / 512) as srfft.cc:385-394 builds it
+  unsigned stage;                    // slots of the points lane + 64 r the lane writes when it windows a frame
+};
+
+__device__ __forceinline__ void MakeFftLane(FftLane &c, int lane, const LdsTables &tab) {
+  c.active = 0;
+#pragma unroll
+  for (int pass = 0; pass < kNumPasses - 1; ++pass) {
+    const int logm = kLogCplx - pass;
+    const int q = (1 << logm) / 4;            // butterflies per block
+    const int first = tab.pass_start[pass];
+    const int nblk = tab.pass_start[pass + 1] - first;
+    const int b = lane / q, n = lane % q;
+    c.pts[pass] = 0;
+    if (b < nblk) {
+      const int i0 = tab.blk_off[first + b] + n;
+      c.pts[pass] = FftSlot(i0) | (FftSlot(i0 + q) << 8) | (FftSlot(i0 + 2 * q) << 16) | ((unsigned)FftSlot(i0 + 3 * q) << 24);
+      c.active |= 1u << pass;
+    }
+    if (logm >= 4) {
+      const float *tw = tab.tw + tab.tw_off[logm];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) c.tw[pass][j] = tw[j * q + n];
+    }
   }
+  const int first = tab.pass_start[kNumPasses - 1];
+  const int nblk = tab.pass_start[kNumPasses] - first;
+  c.two = 0; c.post = 0; c.stage = 0;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int b = lane + kWave * r;
+    if (b < nblk) {
+      const int off = tab.blk_off[first + b];
+      c.two |= (unsigned)(FftSlot(off) | (FftSlot(off + 1) << 8)) << (16 * r);
+      c.active |= 1u << (8 + r);
+    }
+    const int k = 1 + lane + kWave * r;
+    c.post |= (unsigned)(FftSlot(tab.bitrev[k]) | (FftSlot(tab.bitrev[kFftCplx - k]) << 8)) << (16 * r);
+    c.kre[r] = tab.post_re[k];
+    c.kim[r] = tab.post_im[k];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c.stage |= (unsigned)FftSlot(lane + kWave * r) << (8 * r);
+}
+
+template <int LOGM>
+__device__ __forceinline__ void FftPass(f32x2 *z, int lane, const FftLane &c) {
+  constexpr int pass = kLogCplx - LOGM;
+  constexpr int q = (1 << LOGM) / 4;
+  if (c.active & (1u << pass)) LButterfly<LOGM>(z, c.pts[pass], lane % q, c.tw[pass < 5 ? pass : 0]);
   WaveSync();
 }
 
@@ -142,37 +207,35 @@ __device__ __forceinline__ void CopyTablesToLds(LdsTables &tab, const FrontendTa
 
 // srfft.cc:95-237: the 256-point complex split-radix DIF on the interleaved frame in LDS, one
 // wave, as eight passes over the block schedule; output in bit-reversed order.
-__device__ __forceinline__ void ComplexFft256(f32x2 *s_z, int lane, const LdsTables &tab) {
-  FftPass<8>(s_z, lane, tab);
-  FftPass<7>(s_z, lane, tab);
-  FftPass<6>(s_z, lane, tab);
-  FftPass<5>(s_z, lane, tab);
-  FftPass<4>(s_z, lane, tab);
-  FftPass<3>(s_z, lane, tab);
-  FftPass<2>(s_z, lane, tab);
-  {   // two-point blocks, srfft.cc:140-150
-    const int first = tab.pass_start[kNumPasses - 1];
-    const int nblk = tab.pass_start[kNumPasses] - first;
-    for (int b = lane; b < nblk; b += kWave) {
-      int off = tab.blk_off[first + b];
-      const f32x2 u0 = s_z[off], u1 = s_z[off + 1];
-      s_z[off] = f32x2{u0[0] + u1[0], u0[1] + u1[1]};
-      s_z[off + 1] = f32x2{u0[0] - u1[0], u0[1] - u1[1]};
+__device__ __forceinline__ void ComplexFft256(f32x2 *s_z, int lane, const FftLane &c) {
+  FftPass<8>(s_z, lane, c);
+  FftPass<7>(s_z, lane, c);
+  FftPass<6>(s_z, lane, c);
+  FftPass<5>(s_z, lane, c);
+  FftPass<4>(s_z, lane, c);
+  FftPass<3>(s_z, lane, c);
+  FftPass<2>(s_z, lane, c);
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {   // two-point blocks, srfft.cc:140-150
+    if (c.active & (1u << (8 + r))) {
+      const int a0 = (c.two >> (16 * r)) & 255, a1 = (c.two >> (16 * r + 8)) & 255;
+      const f32x2 u0 = s_z[a0], u1 = s_z[a1];
+      s_z[a0] = f32x2{u0[0] + u1[0], u0[1] + u1[1]};
+      s_z[a1] = f32x2{u0[0] - u1[0], u0[1] - u1[1]};
     }
   }
   WaveSync();
 }
 
-// The real-FFT post-pass for bin k (1..128) and its partner 256 - k: srfft.cc:389-436, with the
-// bit-reversed read of srfft.cc:239-265 folded in.  (a_re, a_im) is bin k, (o_re, o_im) bin 256 - k.
+// The real-FFT post-pass for bin k = 1 + lane + 64 r (1..128) and its partner 256 - k:
+// srfft.cc:389-436, with the bit-reversed read of srfft.cc:239-265 folded in.  (a_re, a_im) is bin k,
+// (o_re, o_im) bin 256 - k.
 struct RealBins { float a_re, a_im, o_re, o_im; };
-__device__ __forceinline__ RealBins RealPostPass(const f32x2 *s_z, const LdsTables &tab, int k) {
-  const int kd = kFftCplx - k;
-  const int jk = tab.bitrev[k], jd = tab.bitrev[kd];
-  const f32x2 zk = s_z[jk], zd = s_z[jd];
+__device__ __forceinline__ RealBins RealPostPass(const f32x2 *s_z, const FftLane &c, int r) {
+  const f32x2 zk = s_z[(c.post >> (16 * r)) & 255], zd = s_z[(c.post >> (16 * r + 8)) & 255];
   const float bk_re = zk[0], bk_im = zk[1];
   const float bd_re = zd[0], bd_im = zd[1];
-  const float kre = tab.post_re[k], kim = tab.post_im[k];
+  const float kre = c.kre[r], kim = c.kim[r];
   const float ck_re = 0.5f * (bk_re + bd_re);
   const float ck_im = 0.5f * (bk_im - bd_im);
   const float dk_re = 0.5f * (bk_im + bd_im);
@@ -205,37 +268,58 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
 
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
+  FftLane fc;
+  MakeFftLane(fc, lane, tab);
+  float win_e[4], win_o[4];                        // the Hamming window at this lane's pairs p = lane + 64 r
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int pidx = lane + kWave * r;
+    win_e[r] = 2 * pidx + 1 < kFrameLength ? tab.window[2 * pidx] : 0.0f;
+    win_o[r] = 2 * pidx + 1 < kFrameLength ? tab.window[2 * pidx + 1] : 0.0f;
+  }
+  const int mel_off = lane < kNumBins ? tab.mel_off[lane] : 0, mel_len = lane < kNumBins ? tab.mel_len[lane] : 0;
+  const float *mel_w = tab.mel_w + (lane < kNumBins ? tab.mel_base[lane] : 0);
   FrameLds &fr = frames[wv];
   float *s_x = fr.x, *s_pow = fr.pw;
   f32x2 *s_z = fr.z;
-  float *s_y = reinterpret_cast<float *>(fr.z);   // the same array as 512 real samples
   const int utt = blockIdx.y;
   const int T = utts.num_frames[utt];
   const SampleT *w0 = wave_pcm + utts.wave_off[utt];
   float *out0 = raw + utts.raw_base[utt] * kNumBins;
 
-  // ---- fbank.cc:74-100: a frame's 400 samples, 7 per lane (lane + 64 r).  The samples of
-  // the wave's NEXT frame are fetched before the current frame is processed.
+  // ---- fbank.cc:74-100: a frame's 400 samples as 200 (even, odd) pairs, pair p = lane + 64 r
+  // (r = 0..3): pair p IS point p of the half-size complex FFT (sample 2p real, 2p + 1 imaginary),
+  // so a lane stores whole points, and the predecessor sample the pre-emphasis needs is the lane's
+  // own even sample or its left neighbour's odd one -- a DPP shift, no trip through LDS.  The
+  // samples of the wave's NEXT frame are fetched before the current frame is processed.
   const int t_step = gridDim.x * kFbankWaves;
-  auto fetch = [&](int t, SampleT (&dst)[7]) {
+  auto fetch = [&](int t, SampleT (&de)[4], SampleT (&dod)[4]) {
     const SampleT *w = w0 + (int64_t)t * kFrameShift;
 #pragma unroll
-    for (int r = 0; r < 7; ++r) {
-      const int i = lane + kWave * r;
-      dst[r] = (t < T && i < kFrameLength) ? w[i] : static_cast<SampleT>(0);
+    for (int r = 0; r < 4; ++r) {
+      const int pidx = lane + kWave * r;
+      const bool in = t < T && 2 * pidx + 1 < kFrameLength;
+      // one load per pair; an utterance may start at any sample, so the pair is only element-aligned
+      struct __attribute__((packed, aligned(sizeof(SampleT)))) Pair { SampleT e, o; };
+      Pair pr = {static_cast<SampleT>(0), static_cast<SampleT>(0)};
+      if (in) pr = *reinterpret_cast<const Pair *>(w + 2 * pidx);
+      de[r] = pr.e;
+      dod[r] = pr.o;
     }
   };
-  SampleT cur_s[7], next_s[7];
-  fetch(blockIdx.x * kFbankWaves + wv, cur_s);
+  SampleT cur_e[4], cur_o[4], next_e[4], next_o[4];
+  fetch(blockIdx.x * kFbankWaves + wv, cur_e, cur_o);
   for (int t = blockIdx.x * kFbankWaves + wv; t < T; t += t_step) {
-    fetch(t + t_step, next_s);
-    float x[7];
+    fetch(t + t_step, next_e, next_o);
+    float xe[4], xo[4];
     bool exact = true;
 #pragma unroll
-    for (int r = 0; r < 7; ++r) {
-      x[r] = static_cast<float>(cur_s[r]);
+    for (int r = 0; r < 4; ++r) {
+      xe[r] = static_cast<float>(cur_e[r]);
+      xo[r] = static_cast<float>(cur_o[r]);
       // integer-valued samples of at most 16 bits: any summation order is exact
-      exact = exact && (fabsf(x[r]) <= 32768.0f) && (x[r] == truncf(x[r]));
+      exact = exact && (fabsf(xe[r]) <= 32768.0f) && (xe[r] == truncf(xe[r]))
+                    && (fabsf(xo[r]) <= 32768.0f) && (xo[r] == truncf(xo[r]));
     }
 
     // ---- fbank.cc:48-52: DC offset = sequential float sum / 400.
@@ -243,16 +327,16 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
     if (__all(exact)) {
       // 400 integers of magnitude <= 2^15: every partial sum is an integer below
       // 2^24, so the tree sum equals the reference's sequential sum bit for bit.
-      float p = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + x[6]);
+      float p = ((xe[0] + xo[0]) + (xe[1] + xo[1])) + ((xe[2] + xo[2]) + (xe[3] + xo[3]));
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
       sum = p;
     } else {
       // general float input: keep the reference's order (one lane, 400 adds)
 #pragma unroll
-      for (int r = 0; r < 7; ++r) {
-        int i = lane + kWave * r;
-        if (i < kFrameLength) s_x[i] = x[r];
+      for (int r = 0; r < 4; ++r) {
+        const int pidx = lane + kWave * r;
+        if (2 * pidx + 1 < kFrameLength) { s_x[2 * pidx] = xe[r]; s_x[2 * pidx + 1] = xo[r]; }
       }
       WaveSync();
       float s = 0;
@@ -262,33 +346,34 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
       WaveSync();
     }
     const float mean = sum / kFrameLength;
-
 #pragma unroll
-    for (int r = 0; r < 7; ++r) {
-      int i = lane + kWave * r;
-      x[r] -= mean;                                   // fbank.cc:53-55
-      if (i < kFrameLength) s_x[i] = x[r];
+    for (int r = 0; r < 4; ++r) {                     // fbank.cc:53-55
+      xe[r] -= mean;
+      xo[r] -= mean;
     }
-    WaveSync();
 
-    // ---- fbank.cc:58-68: pre-emphasis in double (0.97 is a double literal), one
-    // rounding to float, then the Hamming window; zero padding 400..511.  Sample 2n is
-    // the real part and 2n+1 the imaginary part of point n of the half-size complex FFT.
+    // ---- fbank.cc:58-68: pre-emphasis in double (0.97 is a double literal), one rounding to
+    // float, then the Hamming window; zero padding 400..511.  x[i] -= 0.97 x[i - 1] runs from the
+    // top down, so the predecessor is the not-yet-emphasised sample; x[0] takes itself.
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      int i = lane + kWave * r;
-      float y = 0.0f;
-      if (r < 7 && i < kFrameLength) {
-        float prev = s_x[i > 0 ? i - 1 : 0];
-        y = static_cast<float>(static_cast<double>(x[r]) - 0.97 * static_cast<double>(prev));
-        y *= tab.window[i];
+    for (int r = 0; r < 4; ++r) {
+      const int pidx = lane + kWave * r;
+      // sample 2p - 1 = the odd sample of pair p - 1: lane - 1 of the same r, or lane 63 of r - 1
+      float prev_e = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, xo[r]), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+      if (lane == 0) prev_e = r == 0 ? xe[0] : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xo[r > 0 ? r - 1 : 0]), 63));
+      float ye = 0.0f, yo = 0.0f;
+      if (2 * pidx + 1 < kFrameLength) {
+        ye = static_cast<float>(static_cast<double>(xe[r]) - 0.97 * static_cast<double>(prev_e));
+        ye *= win_e[r];
+        yo = static_cast<float>(static_cast<double>(xo[r]) - 0.97 * static_cast<double>(xe[r]));
+        yo *= win_o[r];
       }
-      s_y[i] = y;
+      s_z[(fc.stage >> (8 * r)) & 255] = f32x2{ye, yo};
     }
     WaveSync();
 
     // ---- srfft.cc:95-237 as passes over the block schedule
-    ComplexFft256(s_z, lane, tab);
+    ComplexFft256(s_z, lane, fc);
 
     // ---- bit-reversed read (srfft.cc:239-265), real post-pass (srfft.cc:389-436)
     // and power spectrum (fbank.cc:193-211) fused: bin k and its partner 256-k.
@@ -296,7 +381,7 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
     for (int r = 0; r < 2; ++r) {
       const int k = 1 + lane + kWave * r;            // 1..128
       const int kd = kFftCplx - k;
-      const RealBins rb = RealPostPass(s_z, tab, k);
+      const RealBins rb = RealPostPass(s_z, fc, r);
       s_pow[k] = rb.a_re * rb.a_re + rb.a_im * rb.a_im;
       if (kd != k) s_pow[kd] = rb.o_re * rb.o_re + rb.o_im * rb.o_im;
     }
@@ -311,16 +396,22 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
     // ---- fbank.cc:165-184 (sequential float dot per bin, vector.cc:252-262),
     // floor FLT_EPSILON and log (fbank.cc:244-245; the C library's logf, pk_logf.h)
     if (lane < kNumBins) {
-      const int off = tab.mel_off[lane], len = tab.mel_len[lane];
-      const float *mw = tab.mel_w + tab.mel_base[lane];
+      // (two taps per trip: each pair of neighbouring operands is one ds_read2_b32)
       float e = 0.0f;
-      for (int j = 0; j < len; ++j) e += mw[j] * s_pow[off + j];
+      const float *pw = s_pow + mel_off;
+      int j = 0;
+      for (; j + 1 < mel_len; j += 2) {
+        const float w0 = mel_w[j], w1 = mel_w[j + 1], p0 = pw[j], p1 = pw[j + 1];
+        e += w0 * p0;
+        e += w1 * p1;
+      }
+      if (j < mel_len) e += mel_w[j] * pw[j];
       if (e < 1.1920928955078125e-07f) e = 1.1920928955078125e-07f;
       out0[(int64_t)t * kNumBins + lane] = LogfRestated(e, tab.logf_tab);
     }
     WaveSync();
 #pragma unroll
-    for (int r = 0; r < 7; ++r) cur_s[r] = next_s[r];
+    for (int r = 0; r < 4; ++r) { cur_e[r] = next_e[r]; cur_o[r] = next_o[r]; }
   }
 }
 
@@ -560,17 +651,19 @@ __global__ __launch_bounds__(kWave) void Srfft512TestKernel(const float *__restr
   CopyTablesToLds(tab, gtab);
   __syncthreads();
   const int lane = threadIdx.x;
+  FftLane fc;
+  MakeFftLane(fc, lane, tab);
   for (int f = blockIdx.x; f < n; f += gridDim.x) {
     const float *x = frames + (int64_t)f * kFftSize;
     float *y = out + (int64_t)f * kFftSize;
-    for (int i = lane; i < kFftCplx; i += kWave) s_z[i] = f32x2{x[2 * i], x[2 * i + 1]};
+    for (int i = lane; i < kFftCplx; i += kWave) s_z[FftSlot(i)] = f32x2{x[2 * i], x[2 * i + 1]};
     WaveSync();
-    ComplexFft256(s_z, lane, tab);
+    ComplexFft256(s_z, lane, fc);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int k = 1 + lane + kWave * r;
       const int kd = kFftCplx - k;
-      const RealBins rb = RealPostPass(s_z, tab, k);
+      const RealBins rb = RealPostPass(s_z, fc, r);
       y[2 * k] = rb.a_re;
       y[2 * k + 1] = rb.a_im;
       if (kd != k) { y[2 * kd] = rb.o_re; y[2 * kd + 1] = rb.o_im; }
