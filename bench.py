@@ -472,6 +472,9 @@ def main():
             gbs = bpf * frames_per_step / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             out["stage_roofline"][k] = {"bound": "hbm", "bytes_per_frame": bpf, "achieved": gbs,
                                         "peak": hbm_peak, "unit": "GB/s", "frac": gbs / hbm_peak}
+        # SURVEY 8(d) prices the front-end against HBM by contract; what limits it in practice (PMC):
+        out["stage_roofline"]["fbank"]["limited_by"] = "LDS pipe (profiles/r02_fbank_lds.txt, DESIGN.md 3.2)"
+        out["stage_roofline"]["cmvn"]["limited_by"] = "the serial window-sum recurrence, one rounding per frame (DESIGN.md 3.3)" 
         if args.model == "S" and args.batch == 256 and gemm_launches and args.precision == "f32":
             traffic, source = measured_traffic()
             out["roofline"]["traffic"] = traffic
