@@ -26,25 +26,40 @@
 extern "C" {
 #endif
 
-/* ---- data-layout contract (field order and meaning as in the reference) ---- */
+/* ---- data-layout contract (field order and meaning as in the reference) ----
+ * Inside the reference tree (include/reference_binding/decodable.h is the file that takes the
+ * place of src/decodable.h there) the reference's own matrix.h / vector.h / nnet.h come first
+ * and their declarations are the ones used: the guards below are the reference's include guards
+ * (matrix.h:5, vector.h:26) and layer-kind macros (nnet.h:14-17).                              */
 
 /* matrix.h:20-24 -- column-major; memory is [ncol][nrow], i.e. for features and
  * log-likelihoods one frame (column) is contiguous.                              */
+#ifndef POCKETKALDI_MATRIX_H_   /* inside the reference tree matrix.h has already declared it */
 typedef struct pk_matrix_t {
   int ncol;
   int nrow;
   float *data;
 } pk_matrix_t;
+#endif
 
 /* vector.h:39-42 */
+#ifndef POCKETKALDI_VECTOR_H_   /* likewise vector.h */
 typedef struct pk_vector_t {
   int dim;
   float *data;
 } pk_vector_t;
+#endif
 
 /* Stands where `AcousticModel *` stands in the reference (am.h:23-52): holds the
  * nnet weights (in HBM), log-priors, context and the tid->pdf map (host).        */
+#ifdef PK_MI355_AM_T            /* reference_binding/decodable.h: the handle keeps the NAME the
+                                   reference's translation units use for this pointer
+                                   (pocketkaldi::AcousticModel, decodable.h:17, pocketkaldi.h:38);
+                                   across the C ABI it is the same opaque pointer                 */
+typedef PK_MI355_AM_T pk_mi355_am_t;
+#else
 typedef struct pk_mi355_am pk_mi355_am_t;
+#endif
 
 /* decodable.h:15-18 -- same size and field offsets on LP64 (16 + 8 bytes).       */
 typedef struct pk_decodable_t {
@@ -53,12 +68,14 @@ typedef struct pk_decodable_t {
 } pk_decodable_t;
 
 /* Layer kinds, nnet.h:13-16 / nnet.h:28-33 */
+#ifndef PK_NNET_LINEAR_LAYER    /* nnet.h #defines the same names to the same values */
 enum {
   PK_NNET_LINEAR_LAYER = 0,
   PK_NNET_RELU_LAYER = 1,
   PK_NNET_NORMALIZE_LAYER = 2,
   PK_NNET_SOFTMAX_LAYER = 3
 };
+#endif
 
 /* Error codes */
 enum {
