@@ -29,20 +29,36 @@ sys.path.insert(0, REPO)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 FP16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
+# what "bit-identical" is measured against: the cblas-dependent reference files
+# cannot be built in this image, so the whole-path pin is the oracle, itself pinned as far as the reference allows
+PARITY_PIN = ("bit-identical to the oracle restatement (oracle/pk_oracle.c; bitwise-pinned to the reference's srfft.cc and gemm.cc + gemm_haswell.cc compiled here, fbank/CMVN pinned to the reference's Kaldi dumps at 3e-5, layers to nnet_test.cc's answers)")
 
 
 def measured_traffic():
     """HBM bytes per GEMM launch from the newest committed PMC passes (profiles/rNN_pmc_traffic.json):
     bench.py cannot run rocprofv3 around itself, so the number is the OFFLINE measurement of this
-    same command (tools/profile_gpu.sh), and the bench line says so in roofline.traffic_source."""
+    same command (tools/profile_gpu.sh), and the bench line says so in roofline.traffic_source.
+    The file records the hash of the GEMM kernel's sources it was measured on; when the library
+    running now was built from other GEMM sources the figure is NOT reported (traffic = null and
+    the reason instead) -- a stale number never travels silently."""
     import glob
+    from pocketkaldi_amd import build as pkbuild
+    now = pkbuild.gemm_source_hash()
     for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")), reverse=True):
         try:
             with open(path) as f:
-                return json.load(f)["gemm_avg_hbm_bytes_per_launch"], os.path.relpath(path, REPO)
+                d = json.load(f)
+            value = d["gemm_avg_hbm_bytes_per_launch"]
         except Exception:
             continue
-    return None, None
+        rel = os.path.relpath(path, REPO)
+        then = (d.get("measured_on") or {}).get("gemm_source_hash")
+        if then != now:
+            return None, ("%s was measured on GEMM sources %s, this library is built from %s: not reported "
+                          "(re-run tools/profile_gpu.sh S + tools/make_profiles.py)" % (rel, then, now))
+        return value, ("%s (offline rocprofv3 PMC passes of this command on the same GEMM sources, gemm_source_hash %s; "
+                       "FETCH_SIZE x 2 + WRITE_SIZE per launch; not measured in this run)" % (rel, now))
+    return None, "no profiles/r*_pmc_traffic.json"
 
 
 def cpu_baseline(model_name, seconds, budget_s):
@@ -306,7 +322,7 @@ def main():
                          "contract); f16: plain fp16 operands, one MFMA per product, OUTSIDE the contract (~1e-3)")
     ap.add_argument("--softmax", default="stable", choices=["stable", "reference"],
                     help="stable: overflow-safe log-softmax tail (default); reference: the reference's softmax "
-                         "operations one by one -- with f32 the whole path is then bit-identical to the CPU path")
+                         "operations one by one -- with f32 the whole path is then bit-identical to the oracle restatement of the CPU path")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo = rehearsal of the multi-rank flow, e.g. two ranks on ONE GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -360,6 +376,7 @@ def main():
     frames_per_step = bs.total_frames()
 
     # ---- broadcast check: every rank scores utterance 0 with its replica
+    replica_check = "not run (no process group)"
     if world > 1 or tdist.is_initialized():
         chk = pk.BatchScorer(am, synth.global_cmvn_stats(), 1, 16000)
         chk.set_waves([synth.utterance(0, 1.0)])
@@ -368,6 +385,7 @@ def main():
         if not pkdist.all_ranks_agree(s, cdev):
             raise SystemExit("weight broadcast mismatch across ranks")
         chk.close()
+        replica_check = "passed"
 
     def timed_steps(scorer):
         """W untimed + K timed passes bracketed by barrier + device sync.  The per-kernel HIP events
@@ -408,7 +426,7 @@ def main():
                  "ms_per_step": dt2 / args.steps * 1e3,
                  "gemm_tflops_algorithmic": (am2.flops_per_frame() * frames_per_step / (g2 * 1e-3) / 1e12) if g2 > 0 else 0.0,
                  "stage_ms_per_step": {k: tm2[k][0] for k in pk.KINDS},
-                 "parity": "f32: affine layers bit-identical to the reference SGEMM; f16x3: split-fp16 operands on the "
+                 "parity": "f32: affine layers bit-identical to committed outputs of the reference's own SGEMM (gemm.cc + gemm_haswell.cc built here); f16x3: split-fp16 operands on the "
                            "fp16 matrix cores, log-likelihoods within 1e-4*max(|ref|,1) (measured ~1e-6), tests/test_gpu_parity.py"}
         bs2.close()
 
@@ -421,7 +439,7 @@ def main():
         dt3, tm3 = timed_steps(bs3)
         ref_softmax = {"softmax": "reference", "value": total_frames * args.steps / dt3, "unit": "frames/s",
                        "ms_per_step": dt3 / args.steps * 1e3, "stage_ms_per_step": {k: tm3[k][0] for k in pk.KINDS},
-                       "parity": "every stage bit-identical to the reference CPU path (tests/test_gpu_parity.py::"
+                       "parity": "every stage %s (tests/test_gpu_parity.py::" % PARITY_PIN +
                                  "test_reference_softmax_whole_path_is_bit_identical_to_the_reference)"}
         bs3.close()
         am.set_softmax("stable")
@@ -447,7 +465,9 @@ def main():
                        "acoustic_model": args.model, "softmax": args.softmax, "utterances_per_gpu": args.batch,
                        "frames_per_gpu_per_step": int(frames_per_step),
                        "parallelism": "utterance-sharded x%d, weights broadcast once (%s)" % (
-                           world, "RCCL" if args.backend == "nccl" else "gloo rehearsal")},
+                           world, "RCCL" if args.backend == "nccl" else "gloo rehearsal"),
+                       "collective": {"backend": args.backend, "process_group": bool(tdist.is_initialized()),
+                                      "replica_check": replica_check}},
             "roofline": {"bound": "mfma",
                          "kernel": ("GemmKernel (fp32 MFMA affine layers, %d launches/step)" if args.precision == "f32" else
                                     "GemmF16Kernel (fp16 MFMA, 3 MFMA per algorithmic product, %d launches/step)") % gemm_launches,
@@ -478,8 +498,7 @@ def main():
         if args.model == "S" and args.batch == 256 and gemm_launches and args.precision == "f32":
             traffic, source = measured_traffic()
             out["roofline"]["traffic"] = traffic
-            out["roofline"]["traffic_source"] = None if source is None else (
-                "%s (offline rocprofv3 PMC passes of this command, FETCH_SIZE x 2 + WRITE_SIZE per launch; not measured in this run)" % source)
+            out["roofline"]["traffic_source"] = source
             # operands read once + output written once, averaged over the launches of a step
             # (layer 1 reads the 40-dim features, the splice is a view)
             lay = [(40, 440, 1024)] + [(1024, 1024, 1024)] * 3 + [(1024, 1024, 3000)]

@@ -192,9 +192,19 @@ size_t pk_mi355_am_blob_bytes(const pk_mi355_am_t *am);
  * before scoring), or NULL: the call then uses a stream of its own and returns when the
  * broadcast has completed.  tid2pdf and the layer structure are host-side and are NOT sent: every
  * rank reads the (small) tid2pdf file itself or builds the same structure, as bench.py does.
- * RCCL is bound at run time from the process (the copy the communicator was created with), or
- * from librccl.so.1 / $PK_MI355_RCCL_LIB: libpk_mi355.so has no link-time dependency on it.     */
+ * RCCL is bound at run time to the copy ALREADY LOADED in the process -- the one the communicator
+ * was created with (global scope, or RTLD_LOCAL as under Python: found by soname) -- or to
+ * $PK_MI355_RCCL_LIB when set; a second copy is never loaded implicitly.  libpk_mi355.so has no
+ * link-time dependency on RCCL.  Behaviour at more than one rank has been exercised only through
+ * the Python path's gloo rehearsal so far.                                 */
 int pk_mi355_am_broadcast(pk_mi355_am_t *am, void *rccl_comm, int root, void *stream);
+/* Out-of-place form: every rank still RECEIVES into `am`'s blob; on the root the bytes sent are
+ * `src`'s blob (a second model with the same layer structure on the same device, e.g. one just
+ * read from new files while `am` keeps serving).  src == NULL is pk_mi355_am_broadcast.  At one
+ * rank this is RCCL copying src's blob into am's -- the form the one-GPU tests use to show that the
+ * collective really writes the destination model's weights.                                     */
+int pk_mi355_am_broadcast_from(pk_mi355_am_t *am, pk_mi355_am_t *src, void *rccl_comm, int root,
+                               void *stream);
 
 /* Nnet::Propagate, nnet.cc:149-163: in {ncol = T, nrow = in_dim} host ->
  * out {ncol = T, nrow = out_dim} host (out->data is (re)allocated with malloc). */
@@ -263,8 +273,10 @@ int pk_mi355_batch_fetch(pk_mi355_batch_t *b, int utt, pk_decodable_t *out);
  * and hand it to the pk_decodable_* functions only.  pk_decodable_destroy on such a view
  * frees nothing of the caller's and may happen at any time, also after pk_mi355_batch_destroy
  * (pocketkaldi.cc:247 destroys its decodable unconditionally): the arena is released when the
- * batch is gone AND the views of its last fetch_all have been destroyed.  The CONTENTS of the views
- * are valid until the batch is scored again or destroyed.  With sync == 0 the copy is queued on
+ * batch is gone AND the views of its last fetch_all have been destroyed (each fetch_all is a
+ * generation of its own: destroying views of an earlier one never releases memory under the
+ * current ones).  Rely on the CONTENTS of the views only until the batch is scored again or
+ * destroyed; the views of the LAST fetch_all in fact stay readable until the last of them goes.  With sync == 0 the copy is queued on
  * the device's result stream, ordered after this batch's scoring and before anything queued
  * later on the batch's stream; pk_mi355_batch_synchronize completes it, so it overlaps another
  * batch's scoring.                                                                           */

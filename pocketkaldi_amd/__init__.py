@@ -62,7 +62,7 @@ EXPORTS = [
     "pk_mi355_batch_score", "pk_mi355_batch_synchronize", "pk_mi355_batch_num_utts",
     "pk_mi355_batch_num_frames", "pk_mi355_batch_total_frames", "pk_mi355_batch_loglik_device",
     "pk_mi355_batch_fetch", "pk_mi355_batch_fetch_all", "pk_mi355_batch_fetch_fbank", "pk_mi355_batch_fetch_cmvn", "pk_mi355_test_logf",
-    "pk_mi355_test_srfft512", "pk_mi355_am_broadcast",
+    "pk_mi355_test_srfft512", "pk_mi355_am_broadcast", "pk_mi355_am_broadcast_from",
     "pk_mi355_batch_gather_loglik", "pk_mi355_device_malloc", "pk_mi355_device_free", "pk_mi355_memcpy",
     "pk_mi355_host_malloc", "pk_mi355_host_free",
     "pk_mi355_batch_stream", "pk_mi355_batch_enable_timing", "pk_mi355_batch_get_timing",
@@ -156,6 +156,7 @@ def lib():
     L.pk_mi355_test_logf.argtypes = [f32p, C.c_int, f32p]
     L.pk_mi355_test_srfft512.argtypes = [f32p, C.c_int, f32p]
     L.pk_mi355_am_broadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.pk_mi355_am_broadcast_from.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.pk_mi355_batch_gather_loglik.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.pk_mi355_device_malloc.restype = C.c_void_p
     L.pk_mi355_device_malloc.argtypes = [C.c_size_t]
@@ -355,10 +356,11 @@ class AcousticModel:
         """(device pointer, bytes) of the packed weights, for the RCCL broadcast."""
         return lib().pk_mi355_am_blob_device_ptr(self._h), lib().pk_mi355_am_blob_bytes(self._h)
 
-    def broadcast(self, rccl_comm, root=0, stream=None):
-        """pk_mi355_am_broadcast: one ncclBroadcast of the blob over the caller's ncclComm_t (an integer handle)."""
-        _check(lib().pk_mi355_am_broadcast(self._h, C.c_void_p(rccl_comm), int(root),
-                                           None if stream is None else C.c_void_p(stream)))
+    def broadcast(self, rccl_comm, root=0, stream=None, src=None):
+        """pk_mi355_am_broadcast[_from]: one ncclBroadcast into this model's blob over the caller's ncclComm_t
+        (an integer handle); with src, the root sends that model's blob instead of its own."""
+        _check(lib().pk_mi355_am_broadcast_from(self._h, None if src is None else src.handle, C.c_void_p(rccl_comm),
+                                                int(root), None if stream is None else C.c_void_p(stream)))
 
     def propagate(self, x):
         """Nnet::Propagate (nnet.cc:149-163): x [T][in_dim] -> [T][out_dim]."""

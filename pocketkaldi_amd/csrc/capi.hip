@@ -14,6 +14,7 @@
 #include <string>
 #include <mutex>
 #include <utility>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/pk_mi355.h"
@@ -523,63 +524,86 @@ int ResizeHostMatrix(pk_matrix_t *m, int nrow, int ncol) {
 // Page-locked host arenas of pk_mi355_batch_fetch_all.  A decodable handed out by fetch_all is a
 // VIEW into its batch's arena; pk_decodable_destroy must not free() such a pointer, and the
 // reference's caller destroys its decodable unconditionally, whenever it likes
-// (pocketkaldi.cc:247) -- also after the batch is gone.  So the arena is shared property: it
-// counts the views handed out by the last fetch_all, and the page-locked memory is released when
-// the batch has been destroyed AND the last of those views has been destroyed, whichever comes
-// last.  (A caller that never destroys its views keeps the arena until the process ends.)
+// (pocketkaldi.cc:247) -- also after the batch is gone.  So the arena is shared property: the
+// page-locked memory is released when the batch has been destroyed AND the views of its LAST
+// fetch_all have been destroyed, whichever comes last.  (A caller that never destroys its views
+// keeps the arena until the process ends.)
+//
+// Every fetch_all makes one ViewGen -- the generation its views belong to -- and a view's `am` field
+// points at it (tagged, bit 0; opaque to every caller, the four pk_decodable_* functions resolve it).
+// A view therefore always decrements the count of ITS OWN generation: a stale view of an earlier
+// fetch_all, or of another batch whose arena once occupied the same addresses, can never drive the
+// current generation's count to zero under views that are still outstanding (the
+// counts used to be found by address range).  Whether a decodable is a view is not guessed from its
+// address either, so pk_decodable_destroy free()s exactly the matrices malloc() made.
 namespace {
 std::mutex g_arena_mu;
-struct Arena {
-  char *lo, *hi;
-  int live_views;      // views of the last fetch_all not yet destroyed
-  bool batch_alive;
+struct ArenaRec;
+struct ViewGen {
+  pk_mi355_am_t *am;     // what Untag() resolves a view's handle to
+  ArenaRec *arena;       // valid while `current`
+  int live;              // views of this generation not yet destroyed
+  bool current;          // the batch's latest fetch_all
 };
-std::vector<Arena> g_arenas;
-// Whether a decodable is a view is NOT guessed from its address: fetch_all tags the model handle it
-// stores in the view (bit 0 of pk_decodable_t.am, opaque to every caller; the four pk_decodable_*
-// functions mask it), so pk_decodable_destroy free()s exactly the matrices malloc() made.
-inline pk_mi355_am_t *TagView(pk_mi355_am_t *am) { return reinterpret_cast<pk_mi355_am_t *>(reinterpret_cast<uintptr_t>(am) | 1u); }
-inline bool IsView(const pk_mi355_am_t *am) { return (reinterpret_cast<uintptr_t>(am) & 1u) != 0; }
-inline pk_mi355_am_t *Untag(pk_mi355_am_t *am) { return reinterpret_cast<pk_mi355_am_t *>(reinterpret_cast<uintptr_t>(am) & ~uintptr_t(1)); }
+struct ArenaRec {
+  void *mem;
+  bool batch_alive;
+  ViewGen *cur;
+};
+// live generations: a handle that is not in here (a view destroyed twice through a bitwise copy)
+// is ignored instead of dereferenced
+std::unordered_set<const ViewGen *> g_gens;
 
-void RegisterArena(void *p, size_t bytes) {
+inline bool IsView(const pk_mi355_am_t *am) { return (reinterpret_cast<uintptr_t>(am) & 1u) != 0; }
+inline ViewGen *GenOf(const pk_mi355_am_t *am) { return reinterpret_cast<ViewGen *>(reinterpret_cast<uintptr_t>(am) & ~uintptr_t(1)); }
+inline pk_mi355_am_t *TagView(ViewGen *g) { return reinterpret_cast<pk_mi355_am_t *>(reinterpret_cast<uintptr_t>(g) | 1u); }
+// the model behind a decodable's handle (lock-free: a live view keeps its generation alive)
+inline pk_mi355_am_t *Untag(pk_mi355_am_t *am) { return IsView(am) ? GenOf(am)->am : am; }
+
+ArenaRec *RegisterArena(void *p) { return new ArenaRec{p, true, nullptr}; }
+// a new fetch_all: its generation replaces the previous one, whose outstanding views are void by
+// contract (they still own their generation record, nothing else)
+pk_mi355_am_t *NewViewGen(ArenaRec *a, pk_mi355_am_t *am, int views) {
   std::lock_guard<std::mutex> g(g_arena_mu);
-  g_arenas.push_back(Arena{static_cast<char *>(p), static_cast<char *>(p) + bytes, 0, true});
-}
-void SetArenaViews(const void *p, int views) {
-  std::lock_guard<std::mutex> g(g_arena_mu);
-  for (auto &a : g_arenas)
-    if (a.lo == p) a.live_views = views;
-}
-// The batch is going away: release the arena now, or leave that to the last view.
-void RetireArena(void *p) {
-  bool release = false;
-  {
-    std::lock_guard<std::mutex> g(g_arena_mu);
-    for (size_t i = 0; i < g_arenas.size(); ++i)
-      if (g_arenas[i].lo == p) {
-        g_arenas[i].batch_alive = false;
-        if (g_arenas[i].live_views <= 0) { g_arenas.erase(g_arenas.begin() + i); release = true; }
-        break;
-      }
+  if (a->cur) {
+    a->cur->current = false;
+    if (a->cur->live <= 0) { g_gens.erase(a->cur); delete a->cur; }
   }
-  if (release) hipHostFree(p);
+  a->cur = new ViewGen{am, a, views, true};
+  g_gens.insert(a->cur);
+  return TagView(a->cur);
 }
-// pk_decodable_destroy on a view whose matrix is `p`: one view fewer; the last one of a batch that is
-// gone releases the arena.  (A view of an EARLIER fetch_all, destroyed late, finds a count that is
-// not its own, or no arena at all: nothing to do -- it never owned anything.)
-void ReleaseArenaView(const void *p) {
-  if (!p) return;
+// The batch is going away: release the arena now, or leave that to the last view of its last fetch_all.
+void RetireArena(ArenaRec *a) {
   void *release = nullptr;
   {
     std::lock_guard<std::mutex> g(g_arena_mu);
-    for (size_t i = 0; i < g_arenas.size(); ++i) {
-      Arena &a = g_arenas[i];
-      if (static_cast<const char *>(p) < a.lo || static_cast<const char *>(p) >= a.hi) continue;
-      if (a.live_views > 0) --a.live_views;
-      if (!a.batch_alive && a.live_views == 0) { release = a.lo; g_arenas.erase(g_arenas.begin() + i); }
-      break;
+    a->batch_alive = false;
+    if (!a->cur || a->cur->live <= 0) {
+      if (a->cur) { g_gens.erase(a->cur); delete a->cur; }
+      release = a->mem;
+      delete a;
     }
+  }
+  if (release) hipHostFree(release);
+}
+// pk_decodable_destroy on a view: one view fewer in ITS generation; the last view of the current
+// generation of a batch that is gone releases the arena.
+void ReleaseArenaView(pk_mi355_am_t *handle) {
+  void *release = nullptr;
+  {
+    std::lock_guard<std::mutex> g(g_arena_mu);
+    ViewGen *v = GenOf(handle);
+    if (!g_gens.count(v)) return;                 // generation already gone: a copy destroyed twice
+    if (--v->live > 0) return;
+    if (v->current) {
+      ArenaRec *a = v->arena;
+      if (a->batch_alive) return;                 // the batch releases it (RetireArena) or re-uses it
+      release = a->mem;
+      delete a;
+    }
+    g_gens.erase(v);
+    delete v;
   }
   if (release) hipHostFree(release);
 }
@@ -973,15 +997,29 @@ NcclErrorStringFn g_nccl_error_string = nullptr;
 int BindRccl() {
   std::lock_guard<std::mutex> g(g_rccl_mu);
   if (g_nccl_broadcast) return 0;
-  // the copy already in the process first: the communicator belongs to it
-  void *sym = dlsym(RTLD_DEFAULT, "ncclBroadcast");
+  // The communicator belongs to ONE copy of RCCL: the one the caller created it with, which is
+  // therefore already loaded.  Bind to that copy and never load a second one behind the caller's
+  // back (a foreign ncclComm_t handed to another copy is undefined behaviour):
+  //   1. $PK_MI355_RCCL_LIB, when set, names the library explicitly (loaded if need be);
+  //   2. a copy visible in the global scope (a host linked with -lrccl);
+  //   3. a copy loaded RTLD_LOCAL (Python / torch): found by soname with RTLD_NOLOAD.
   void *h = nullptr;
-  if (!sym) {
-    const char *path = getenv("PK_MI355_RCCL_LIB");
-    h = dlopen(path ? path : "librccl.so.1", RTLD_NOW | RTLD_LOCAL);   // an already loaded copy is matched by soname
-    if (!h && !path) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!h) return Fail(PK_MI355_E_DEVICE, "RCCL is not loaded and cannot be opened: %s", dlerror());
+  void *sym = nullptr;
+  const char *path = getenv("PK_MI355_RCCL_LIB");
+  if (path && *path) {
+    h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return Fail(PK_MI355_E_DEVICE, "PK_MI355_RCCL_LIB=%s cannot be opened: %s", path, dlerror());
     sym = dlsym(h, "ncclBroadcast");
+  } else {
+    sym = dlsym(RTLD_DEFAULT, "ncclBroadcast");
+    if (!sym) {
+      h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+      if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+      if (!h)
+        return Fail(PK_MI355_E_DEVICE, "no RCCL is loaded in this process (the communicator's library must be; "
+                                       "or name it in PK_MI355_RCCL_LIB)");
+      sym = dlsym(h, "ncclBroadcast");
+    }
   }
   if (!sym) return Fail(PK_MI355_E_DEVICE, "ncclBroadcast not found in RCCL");
   void *es = h ? dlsym(h, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString");
@@ -991,8 +1029,10 @@ int BindRccl() {
 }
 }  // namespace
 
-int pk_mi355_am_broadcast(pk_mi355_am_t *am, void *rccl_comm, int root, void *stream) {
+int pk_mi355_am_broadcast_from(pk_mi355_am_t *am, pk_mi355_am_t *src, void *rccl_comm, int root, void *stream) {
   if (!am || !am->finalized) return Fail(PK_MI355_E_STATE, "model not finalized");
+  if (src && (!src->finalized || src->blob_floats != am->blob_floats || src->device != am->device))
+    return Fail(PK_MI355_E_INVALID, "source model does not have the destination's blob layout / device");
   if (!rccl_comm) return Fail(PK_MI355_E_INVALID, "null RCCL communicator");
   if (root < 0) return Fail(PK_MI355_E_INVALID, "bad root rank %d", root);
   int rc = UseDevice(am->device);
@@ -1003,10 +1043,10 @@ int pk_mi355_am_broadcast(pk_mi355_am_t *am, void *rccl_comm, int root, void *st
     HIP_TRY(hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
     s = own;
   }
-  // in place: send buffer = receive buffer = this rank's blob (same size on every rank: the
-  // layout depends on the layer structure only)
-  const int nr = g_nccl_broadcast(am->d_blob, am->d_blob, am->blob_floats * sizeof(float), /*ncclUint8*/ 1, root,
-                                  rccl_comm, s);
+  // receive buffer = this rank's blob (same size on every rank: the layout depends on the layer
+  // structure only); send buffer = the same blob (in place) or, on the root, `src`'s
+  const int nr = g_nccl_broadcast(src ? src->d_blob : am->d_blob, am->d_blob, am->blob_floats * sizeof(float),
+                                  /*ncclUint8*/ 1, root, rccl_comm, s);
   if (nr != 0) {
     if (own) hipStreamDestroy(own);
     return Fail(PK_MI355_E_DEVICE, "ncclBroadcast failed: %s", g_nccl_error_string ? g_nccl_error_string(nr) : "?");
@@ -1017,6 +1057,10 @@ int pk_mi355_am_broadcast(pk_mi355_am_t *am, void *rccl_comm, int root, void *st
     if (e != hipSuccess) return Fail(PK_MI355_E_DEVICE, "broadcast stream: %s", hipGetErrorString(e));
   }
   return 0;
+}
+
+int pk_mi355_am_broadcast(pk_mi355_am_t *am, void *rccl_comm, int root, void *stream) {
+  return pk_mi355_am_broadcast_from(am, nullptr, rccl_comm, root, stream);
 }
 
 int pk_mi355_nnet_propagate(pk_mi355_am_t *am, const pk_matrix_t *in, pk_matrix_t *out) {
@@ -1104,7 +1148,7 @@ void pk_decodable_init(pk_decodable_t *self, pk_mi355_am_t *am, float prob_scale
 void pk_decodable_destroy(pk_decodable_t *self) {
   // matrix.cc:123-128 frees; a decodable handed out by pk_mi355_batch_fetch_all is a view of
   // the batch's page-locked arena (tagged handle) and owns nothing.
-  if (IsView(self->am)) ReleaseArenaView(self->log_prob.data);
+  if (IsView(self->am)) ReleaseArenaView(self->am);
   else free(self->log_prob.data);
   self->log_prob.data = nullptr;
   self->log_prob.nrow = 0;
@@ -1158,6 +1202,7 @@ struct pk_mi355_batch {
   int64_t ldy = 0;
   float *d_ll = nullptr;    // [max_cols][num_pdfs]
   float *h_ll = nullptr;    // page-locked mirror of d_ll (pk_mi355_batch_fetch_all), made on first use
+  ArenaRec *arena = nullptr;  // its shared-ownership record
   hipEvent_t ev_scored = nullptr, ev_fetched = nullptr;
   // Optional second lane for the layer stack (PK_MI355_LANES=2): odd chunks run on their own
   // stream and buffers, so the HBM-bound tail of one chunk overlaps the MFMA-bound GEMMs of the
@@ -1294,7 +1339,7 @@ void pk_mi355_batch_destroy(pk_mi355_batch_t *b) {
   hipFree(b->d_wave); hipFree(b->d_wave_i16);
   hipFree(b->d_wave_off); hipFree(b->d_raw_base); hipFree(b->d_pad_base); hipFree(b->d_T);
   hipFree(b->d_raw_alloc); hipFree(b->d_yt); hipFree(b->d_y2); hipFree(b->d_ll);
-  if (b->h_ll) RetireArena(b->h_ll);     // released now, or by the last outstanding view
+  if (b->arena) RetireArena(b->arena);   // released now, or by the last outstanding view of the last fetch_all
   if (b->ev_scored) hipEventDestroy(b->ev_scored);
   if (b->ev_fetched) hipEventDestroy(b->ev_fetched);
   if (b->stream) hipStreamDestroy(b->stream);
@@ -1442,7 +1487,7 @@ int pk_mi355_batch_fetch_all(pk_mi355_batch_t *b, pk_decodable_t *out, int num_o
   if (!b->h_ll) {
     const size_t bytes = sizeof(float) * (size_t)b->max_cols * N;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_ll), bytes, hipHostMallocDefault));
-    RegisterArena(b->h_ll, bytes);
+    b->arena = RegisterArena(b->h_ll);
   }
   // One transfer of the used part of d_ll (the 10 rows between two utterances travel too:
   // 1 % at T = 998, and one large copy runs at the link rate).
@@ -1464,16 +1509,14 @@ int pk_mi355_batch_fetch_all(pk_mi355_batch_t *b, pk_decodable_t *out, int num_o
     HIP_TRY(hipEventRecord(b->ev_fetched, rs));
     HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_fetched, 0));
   }
-  int views = 0;
+  pk_mi355_am_t *gen = NewViewGen(b->arena, b->am, num_out);   // the views of an earlier fetch_all are void by contract
   for (int u = 0; u < num_out; ++u) {
     const int T = b->h_T[u];
-    out[u].am = TagView(b->am);
+    out[u].am = gen;
     out[u].log_prob.ncol = T;
     out[u].log_prob.nrow = T > 0 ? N : 0;
     out[u].log_prob.data = T > 0 ? b->h_ll + (size_t)b->h_pad_base[u] * N : nullptr;
-    views += T > 0;
   }
-  SetArenaViews(b->h_ll, views);        // the views of an earlier fetch_all are void by contract
   if (sync) HIP_TRY(hipStreamSynchronize(b->stream));
   return 0;
 }

@@ -35,6 +35,8 @@
 #include <hip/hip_fp16.h>
 
 #include "pk_dma.h"
+#include <mutex>
+
 #include "pk_kernels.h"
 
 namespace pkmi {
@@ -368,13 +370,21 @@ void LaunchGemmF16(const GemmF16Args &a, hipStream_t stream) {
   const int nblk = super_m * super_n * 16;
   dim3 grid(nblk), block(kThreadsF16);
   const size_t lds = kRingF16 * kHalfSlabBytes;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the 128 KiB dynamic-LDS opt-in is a per-DEVICE function attribute: set it once for every device a
+  // thread launches on (models and batches may be driven from several host threads)
+  {
+    static std::mutex mu;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
 #define PK_SET_LDS(R, L, T) hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmF16Kernel<R, L, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-    PK_SET_LDS(true, false, 3); PK_SET_LDS(false, false, 3); PK_SET_LDS(true, true, 3); PK_SET_LDS(false, true, 3);
-    PK_SET_LDS(true, false, 1); PK_SET_LDS(false, false, 1); PK_SET_LDS(true, true, 1); PK_SET_LDS(false, true, 1);
+      PK_SET_LDS(true, false, 3); PK_SET_LDS(false, false, 3); PK_SET_LDS(true, true, 3); PK_SET_LDS(false, true, 3);
+      PK_SET_LDS(true, false, 1); PK_SET_LDS(false, false, 1); PK_SET_LDS(true, true, 1); PK_SET_LDS(false, true, 1);
 #undef PK_SET_LDS
-    attr_set = true;
+      attr_set[dev] = true;
+    }
   }
 #define PK_LAUNCH(R, L, T) hipLaunchKernelGGL((GemmF16Kernel<R, L, T>), grid, block, lds, stream, a)
   if (a.terms == 1) {

@@ -3,7 +3,9 @@
 // pk_mi355_am_broadcast over its RCCL communicator replaces its weights by rank `root`'s.
 // Linked against the system RCCL and libpk_mi355.so; run by tests/test_cpp_host.py (-m gpu).
 // One GPU here, so nranks = 1: the call path (run-time RCCL binding, in-place ncclBroadcast of
-// the device blob, caller stream / own stream) is the one N ranks take.
+// the device blob, caller stream / own stream) is the one N ranks take; the out-of-place form
+// (pk_mi355_am_broadcast_from) shows RCCL writing ANOTHER model's blob.  RCCL has not run this
+// entry with more than one rank yet (no multi-GPU box in the build loop).
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 #include <stdio.h>
@@ -76,6 +78,22 @@ int main() {
                   hipMemcpyDeviceToDevice) == hipSuccess);
   CHECK(pk_mi355_am_broadcast(am, comm, 0, nullptr) == 0);
   CHECK(Score(am) == Score(zero) && Score(am) != want);
+
+  // RCCL itself writes the destination model's weights: `fresh` shares nothing with `real` and
+  // starts from a third pattern (all zeros); the out-of-place form sends real's blob and receives
+  // into fresh's, which at one rank is RCCL copying blob to blob on its own stream
+  pk_mi355_am_t *real = BuildModel(true);
+  pk_mi355_am_t *fresh = BuildModel(false);
+  CHECK(Score(fresh) != want);
+  CHECK(pk_mi355_am_broadcast_from(fresh, real, comm, 0, nullptr) == 0);
+  CHECK(Score(fresh) == want);
+  CHECK(Score(real) == want);
+  // ... and on a caller stream, back to zeros
+  CHECK(pk_mi355_am_broadcast_from(fresh, zero, comm, 0, s) == 0);
+  CHECK(hipStreamSynchronize(s) == hipSuccess);
+  CHECK(Score(fresh) == Score(zero));
+  pk_mi355_am_destroy(fresh);
+  pk_mi355_am_destroy(real);
 
   // misuse is reported, not fatal
   CHECK(pk_mi355_am_broadcast(am, nullptr, 0, nullptr) != 0);

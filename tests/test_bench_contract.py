@@ -40,3 +40,82 @@ def test_bench_line_has_the_contract_keys():
     assert "time-capped" in c["sample"] and "time-capped" in d["cpu_baseline_all_cores"]["sample"]
     # value = frames of all steps / wall time
     assert abs(d["value"] - d["config"]["frames_per_gpu_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def _one_json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.gpu
+def test_driver_launch_shape_two_ranks_on_one_gpu():
+    """BASELINE configs[3]'s launch path: the driver's own command shape for N > 1 -- fresh processes from
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N ...` -- rehearsed with two ranks sharing the one GPU (gloo: two RCCL ranks cannot share
+    a device).  Rank 1 builds zero weights and receives rank 0's through bench.py's own broadcast; bench.py's
+    replica check (every rank scores a common utterance) must pass; rank 0 prints exactly one line whose value
+    is the frames of BOTH ranks over the slowest rank's time."""
+    env = dict(os.environ, PYTHONPATH=REPO)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PK_DIST_FORCE"):
+        env.pop(k, None)
+    r = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo",
+         "--batch", "8", "--seconds", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+        capture_output=True, text=True, cwd=REPO, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert "x2" in d["config"]["parallelism"] and "gloo rehearsal" in d["config"]["parallelism"]
+    per_rank = d["config"]["frames_per_gpu_per_step"]
+    assert per_rank == 8 * 198                         # 2 s -> 198 frames (fbank.cc:35-42), 8 utterances per rank
+    assert abs(d["value"] - 2 * per_rank / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert "cpu_baseline" not in d and "endpoints" not in d and "other_configs" not in d   # N = 1 only
+    assert d["other_precision"]["precision"] == "f16x3" and d["other_precision"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_forced_process_group_runs_the_real_rccl_broadcast_inside_bench():
+    """PK_DIST_FORCE=1 at world 1: bench.py calls init_process_group("nccl") -- RCCL -- and
+    torch.distributed.broadcast on the zero-copy alias of the model's device blob, then its replica check.
+    One rank, so the collective moves nothing between GPUs (RCCL has never seen two ranks in this repository's
+    build loop: DESIGN.md section 6), but every call of the N-rank flow is the real one."""
+    env = dict(os.environ, PYTHONPATH=REPO, PK_DIST_FORCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run(
+        [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--backend", "nccl", "--batch", "8", "--seconds", "2",
+         "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--no-host-endpoints",
+         "--no-other-precision"],
+        capture_output=True, text=True, cwd=REPO, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 1 and "RCCL" in d["config"]["parallelism"]
+    assert d["config"]["collective"] == {"backend": "nccl", "process_group": True, "replica_check": "passed"}
+
+
+def test_offline_traffic_figure_is_tied_to_the_gemm_sources(tmp_path, monkeypatch):
+    """roofline.traffic comes from committed PMC passes; it is reported only when that file says it was
+    measured on the GEMM sources the running library is built from (VERDICT round 2, next #6)."""
+    sys.path.insert(0, REPO)
+    import bench
+    from pocketkaldi_amd import build as B
+    (tmp_path / "profiles").mkdir()
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    assert bench.measured_traffic()[0] is None
+    f = tmp_path / "profiles" / "r09_pmc_traffic.json"
+    f.write_text(json.dumps({"gemm_avg_hbm_bytes_per_launch": 2.5e9, "measured_on": {"gemm_source_hash": "0" * 16}}))
+    value, why = bench.measured_traffic()
+    assert value is None and "not reported" in why
+    f.write_text(json.dumps({"gemm_avg_hbm_bytes_per_launch": 2.5e9, "measured_on": {"gemm_source_hash": B.gemm_source_hash()}}))
+    value, why = bench.measured_traffic()
+    assert value == 2.5e9 and "same GEMM sources" in why

@@ -29,3 +29,22 @@ def test_no_env_override_of_the_product_library(monkeypatch):
     import pocketkaldi_amd as pk
     monkeypatch.setenv("PK_MI355_LIB", "/tmp/other.so")
     assert pk.lib_path() == os.path.join(os.path.dirname(pk.__file__), "libpk_mi355.so")
+
+
+def test_concurrent_builds_are_serialised():
+    """on a fresh tree (stamp git-ignored, so missing) every rank of a torchrun / mp.spawn
+    launch used to compile into the same object files at once.  Three processes that all find the stamp
+    missing: exactly one compiles (flock next to the library), the others wait and find it fresh."""
+    import subprocess
+    import sys
+    B.build()
+    os.unlink(B.STAMP)
+    code = ("import sys, time; sys.path.insert(0, %r); from pocketkaldi_amd import build as B; t = time.time(); "
+            "B.build(); print('built' if time.time() - t > 0 else '', int(not B._stale()))" % os.path.dirname(os.path.dirname(B.HERE + "/")))
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True) for _ in range(3)]
+    outs = [p.communicate()[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all(o.strip().endswith("1") for o in outs), outs
+    assert not B._stale() and open(B.STAMP).read().strip() == B.source_hash()
+    assert not [f for f in os.listdir(B.CSRC) if f.endswith(".o")]            # per-pid objects are removed
+    assert not [f for f in os.listdir(B.HERE) if f.endswith(".tmp")]

@@ -529,6 +529,39 @@ def test_full_size_batch_properties():
     assert_loglik_close(bs.fetch(255).log_prob(), ref)          # (iii)
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+def test_full_size_batch_properties_wide_model(prec):
+    """BASELINE configs[4] at the size the bench times: 256 utterances x 10 s through the wide model
+    (440 -> 6 x 2048 -> 8000): the 256 x 256-tile fp16 kernel at K = 2048 / N = 8000, the 8000-wide tail,
+    131 072-row chunks.  Same size-independent properties as configs[2] above -- (i) total frames,
+    (ii) every frame's likelihoods re-normalise, (iii) an utterance inside the batch has the bits of the
+    same utterance scored alone -- and (iv) one utterance against the oracle at the path's 1e-4."""
+    layers, prior, L, R = synth.model("W")
+    g = synth.global_cmvn_stats()
+    B = 256
+    waves = [synth.utterance(u, 10.0) for u in range(B)]
+    am = pk.AcousticModel(layers, prior, L, R, precision=prec)
+    bs = pk.BatchScorer(am, g, B, sum(len(w) for w in waves))
+    bs.set_waves(waves)
+    bs.score(0.1)
+    assert bs.total_frames() == B * 998                         # (i)
+    logp = np.log(prior.astype(np.float64))
+    solo = pk.BatchScorer(am, g, 1, 160000)
+    for u in (0, 127, 255):
+        ll = bs.fetch(u).log_prob()
+        assert ll.shape == (998, 8000) and np.all(np.isfinite(ll))
+        z = ll.astype(np.float64) / np.float64(np.float32(0.1)) + logp
+        lse = np.log(np.sum(np.exp(z - z.max(axis=1, keepdims=True)), axis=1)) + z.max(axis=1)
+        assert np.max(np.abs(lse)) < 2e-4                       # (ii)
+        solo.set_waves([waves[u]])
+        solo.score(0.1)
+        assert bits_equal(solo.fetch(0).log_prob(), ll)         # (iii)
+    ref = O.Nnet(layers).am_compute(O.cmvn(g, O.Fbank().compute(waves[127])), prior, L, R, 0.1)
+    assert_loglik_close(bs.fetch(127).log_prob(), ref)          # (iv)
+    solo.close()
+    bs.close()
+
+
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
 def test_run_to_run_determinism_under_load(prec):
     """Race screen for the DMA-ring / barrier structure of the GEMM kernels: the same batch scored
@@ -776,8 +809,10 @@ def test_f16x3_spliced_entry_needs_feature_dim_multiple_of_8():
 def test_view_destroyed_after_its_batch_is_safe():
     """VERDICT r1 #10 (gpurun_out/seg.log): the reference's caller destroys its decodable
     unconditionally at the end (pocketkaldi.cc:247), possibly after pk_mi355_batch_destroy.  The
-    arena now lives until the batch AND the views of its last fetch_all are gone: reading a view
-    after the batch is destroyed is still valid, destroying it frees the arena, once."""
+    arena lives until the batch AND the views of its last fetch_all are gone: reading such a view
+    after the batch is destroyed is still valid, destroying the last one frees the arena, once.
+    (include/pk_mi355.h promises less -- contents valid until the batch is scored again or destroyed --
+    the longer lifetime is what makes the reference's unconditional destroy order safe.)"""
     import ctypes as C
     L_ = pk.lib()
     layers, prior, L, R = synth.model("tiny")
@@ -804,8 +839,9 @@ def test_view_destroyed_after_its_batch_is_safe():
     d = pk.Decodable(am, 0.1, np.zeros((5, 40), np.float32))
     assert d.log_prob().shape == (5, 50)
     d.destroy()
-    # the nastiest order: views of an EARLIER fetch_all kept, a later fetch_all's views destroyed, the
-    # batch destroyed, and only then the stale views destroyed -- nothing may reach free()
+    # the nastiest order: the views of an EARLIER fetch_all are destroyed while the views of
+    # the current one are outstanding, then the batch goes -- every view counts against its OWN generation,
+    # so the current views must stay readable until the last of THEM is destroyed
     bs3 = pk.BatchScorer(am, synth.global_cmvn_stats(), 3, sum(len(w) for w in waves[:3]))
     bs3.set_waves(waves[:3])
     bs3.score(0.1)
@@ -814,21 +850,22 @@ def test_view_destroyed_after_its_batch_is_safe():
     assert L_.pk_mi355_batch_fetch_all(bs3._h, stale, 3, 1) == 0
     bs3.score(0.1)
     assert L_.pk_mi355_batch_fetch_all(bs3._h, fresh, 3, 1) == 0
+    assert stale[0].am != fresh[0].am and fresh[0].am == fresh[2].am      # one (opaque) generation handle per fetch_all
     for u in range(3):
-        L_.pk_decodable_destroy(C.byref(stale[u]))      # drives the count of the second fetch_all to zero
-    stale2 = (pk.pk_decodable_t * 3)()
-    assert L_.pk_mi355_batch_fetch_all(bs3._h, stale2, 3, 1) == 0
-    keep = [(stale2[u].log_prob.ncol, stale2[u].log_prob.nrow, stale2[u].log_prob.data, stale2[u].am) for u in range(3)]
-    for u in range(3):
-        L_.pk_decodable_destroy(C.byref(fresh[u]))
+        L_.pk_decodable_destroy(C.byref(stale[u]))      # three stale destroys: the current generation still counts 3
     L_.pk_mi355_batch_destroy(bs3._h)
     bs3._h = None
-    late = (pk.pk_decodable_t * 3)()
-    for u in range(3):                                   # bitwise copies of views whose arena is gone by now
-        late[u].log_prob.ncol, late[u].log_prob.nrow, late[u].log_prob.data, late[u].am = keep[u]   # whole-struct copies
-        L_.pk_decodable_destroy(C.byref(stale2[u]))
     for u in range(3):
-        L_.pk_decodable_destroy(C.byref(late[u]))        # views (tagged handle) of an arena that is gone: a no-op, not a free()
+        lp = fresh[u].log_prob
+        assert bits_equal(np.ctypeslib.as_array(lp.data, shape=(lp.ncol, lp.nrow)), want[u])
+        assert L_.pk_decodable_loglikelihood(C.byref(fresh[u]), 0, 7) == want[u][0, 7]
+    keep = [(fresh[u].log_prob.ncol, fresh[u].log_prob.nrow, fresh[u].log_prob.data, fresh[u].am) for u in range(3)]
+    late = (pk.pk_decodable_t * 3)()
+    for u in range(3):                                   # bitwise copies, destroyed after the originals
+        late[u].log_prob.ncol, late[u].log_prob.nrow, late[u].log_prob.data, late[u].am = keep[u]
+        L_.pk_decodable_destroy(C.byref(fresh[u]))       # the last of these releases the arena
+    for u in range(3):
+        L_.pk_decodable_destroy(C.byref(late[u]))        # views of a generation that is gone: a no-op, not a free()
     # Python mirror: closing the scorer while views are alive, views die later
     bs2 = pk.BatchScorer(am, synth.global_cmvn_stats(), 3, sum(len(w) for w in waves[:3]))
     bs2.set_waves(waves[:3])

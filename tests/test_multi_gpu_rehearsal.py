@@ -73,6 +73,7 @@ def _rank_main(rank, world, port, out_dir, precision):
 def test_two_ranks_on_one_gpu_broadcast_and_score(tmp_path, precision):
     import torch.multiprocessing as mp
     world = 2
+    pk.lib()            # build (if stale) in the parent, once, before any rank exists
     mp.spawn(_rank_main, args=(world, _free_port(), str(tmp_path), precision), nprocs=world, join=True)
     res = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(world)]
     # single-process run over the same utterance ids with the real weights
@@ -122,5 +123,15 @@ def test_c_abi_broadcast_over_a_real_rccl_communicator_at_one_rank():
         assert np.array_equal(pk.Decodable(am, 0.1, feats).log_prob(), want)
         with pytest.raises(pk.PkError):
             am.broadcast(None, root=0)
+        # RCCL writes a DIFFERENT model's blob: `other` shares nothing with `am` and starts from zero
+        # weights; the out-of-place form sends am's blob and receives into other's
+        zl = [(l[0], np.zeros_like(l[1]), np.zeros_like(l[2])) if l[0] == "linear" else l for l in layers]
+        other = pk.AcousticModel(zl, np.full_like(prior, 1.0), L, R)
+        assert not np.array_equal(pk.Decodable(other, 0.1, feats).log_prob(), want)
+        other.broadcast(comm.value, root=0, src=am)
+        assert np.array_equal(pk.Decodable(other, 0.1, feats).log_prob(), want)
+        zero = pk.AcousticModel(zl, np.full_like(prior, 1.0), L, R, precision="f16x3")
+        with pytest.raises(pk.PkError, match="layout"):         # another precision = another blob layout
+            other.broadcast(comm.value, root=0, src=zero)
     finally:
         rccl.ncclCommDestroy(comm)

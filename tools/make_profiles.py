@@ -22,6 +22,36 @@ import sys
 tag = sys.argv[1]
 SRC = "gpurun_out/prof"
 DST = "profiles"
+ALLOW_MIXED = "--allow-mixed" in sys.argv
+
+
+def section_head(sec):
+    """{library_build_hash, gemm_source_hash} tools/profile_gpu.sh recorded when it ran section `sec`."""
+    path = os.path.join(SRC, sec + ".head")
+    if not os.path.exists(path):
+        return {"library_build_hash": None, "gemm_source_hash": None}
+    return dict(kv.split("=", 1) for kv in open(path).read().split())
+
+
+def heads_check():
+    """All sections present must have been measured on ONE library (profile_gpu.sh re-runs
+    single sections, and a summary mixing HEADs under one tag is silently wrong)."""
+    seen = {s: section_head(s)["library_build_hash"] for s in ("S", "W", "B1", "bench")
+            if os.path.exists(os.path.join(SRC, s + ".head"))}
+    if len(set(seen.values())) > 1:
+        msg = "sections measured on different library builds: %s" % seen
+        if not ALLOW_MIXED:
+            raise SystemExit(msg + "  (re-run the stale sections, or pass --allow-mixed: every file then carries its own hash)")
+        print("WARNING:", msg)
+    return seen
+
+
+heads_check()
+try:
+    import subprocess
+    GIT_HEAD = subprocess.check_output(["git", "rev-parse", "HEAD"], text=True).strip()
+except Exception:
+    GIT_HEAD = None
 
 
 def one(pattern, required=True):
@@ -67,16 +97,19 @@ for sec in ("S", "W"):
         if not stats:
             continue
         shutil.copy(stats, os.path.join(DST, "%s_%s_%s_kernel_stats.csv" % (tag, sec, mode)))
-        json.dump(bench_line(os.path.join(SRC, "%s_%s_bench.json" % (sec, mode))),
-                  open(os.path.join(DST, "%s_%s_%s_bench_under_rocprof.json" % (tag, sec, mode)), "w"), indent=1)
+        line = bench_line(os.path.join(SRC, "%s_%s_bench.json" % (sec, mode)))
+        line["measured_on"] = dict(section_head(sec), summarised_at_git_head=GIT_HEAD)
+        json.dump(line, open(os.path.join(DST, "%s_%s_%s_bench_under_rocprof.json" % (tag, sec, mode)), "w"), indent=1)
         wrote += ["%s_%s kernel stats" % (sec, mode)]
     # HBM traffic per launch
-    traffic = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 1 --warmup 1 "
+    head = section_head(sec)
+    head["summarised_at_git_head"] = GIT_HEAD
+    traffic = {"measured_on": head, "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 1 --warmup 1 "
                        "--no-cpu-baseline --no-other-precision --no-other-configs --no-host-endpoints%s [--precision f16x3]` "
                        "(256 utt x 10 s; tools/profile_gpu.sh). Counters are in KB. gfx950 correction per MI355X_MICROARCH.md (HBM "
                        "section): FETCH_SIZE counts 128-B requests at 64 B for wide coalesced reads, so read bytes = 2 x FETCH_SIZE x "
                        "1024; WRITE_SIZE is exact." % (" --model W" if sec == "W" else "")}
-    mfma = {"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY "
+    mfma = {"measured_on": head, "note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY "
                     "SQ_LDS_BANK_CONFLICT (own pass, tools/profile_gpu.sh). mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CU_CYCLES "
                     "* 4 SIMDs); effective_clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration (MI355X_MICROARCH.md, DVFS "
                     "give-back); mfma_rate_frac_of_2p4ghz_peak = mfma_busy * clock / 2.4."}
@@ -131,7 +164,9 @@ if b1:
     open(os.path.join(DST, tag + "_B1_probe.txt"), "w").write("".join(keep))
     wrote += ["B1"]
 if os.path.exists(os.path.join(SRC, "bench.json")):
-    json.dump(bench_line(os.path.join(SRC, "bench.json")), open(os.path.join(DST, tag + "_bench.json"), "w"), indent=1)
+    line = bench_line(os.path.join(SRC, "bench.json"))
+    line["measured_on"] = dict(section_head("bench"), summarised_at_git_head=GIT_HEAD)
+    json.dump(line, open(os.path.join(DST, tag + "_bench.json"), "w"), indent=1)
     wrote += ["bench"]
 # bench.py's roofline.traffic reads profiles/rNN_pmc_traffic.json (newest round first)
 if os.path.exists(os.path.join(DST, tag + "_S_pmc_traffic.json")):

@@ -33,6 +33,8 @@ passes() {   # $1 = tag (S / W), $2 = extra bench args
 }
 
 for s in $SECTIONS; do
+  # what this section measures: hashes of the library's sources (no .git on the GPU box)
+  python3 -m pocketkaldi_amd.build --hashes > $OUT/$s.head
   case $s in
     S) passes S "" ;;
     W) passes W "--model W" ;;
