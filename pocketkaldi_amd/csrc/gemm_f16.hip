@@ -35,6 +35,7 @@
 #include <hip/hip_fp16.h>
 
 #include "pk_dma.h"
+#include <stdlib.h>
 #include <mutex>
 
 #include "pk_kernels.h"
@@ -345,6 +346,238 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
 #endif
 }
 
+// ======================================================================= 16 x 16 x 32 form
+// GemmF16K32Kernel -- the same tile, ring, DMA and data layouts on v_mfma_f32_16x16x32_f16.
+// Why: this chip holds its clock down under fp16 MFMA load, and the clock it holds depends on the
+// MFMA shape (MI355X_MICROARCH.md, DVFS give-back item 7; tools/ubench/mfma_shape_probe.hip on this
+// pool: 16x16x32 1.91 GHz / 1906 TFLOP/s against 1.65 GHz / 1688 for 32x32x16 in bare register
+// loops at equal cycles per flop).  The CDNA3-era k16 forms run at half rate here (same probe), so
+// the k32 of an instruction has to come from two k16 half-slabs:
+//   * a STEP is a PAIR of half-slabs (k32); the ring of four half-slabs is two pair slots; one
+//     barrier per step; the pair after next is fetched into the slot a step has just released;
+//   * lane l of a fragment owns LDS row (l & 15) of its 16-row tile and k-group g = l >> 4:
+//     g = 0, 1 -> k 0..7, 8..15 of the first half-slab, g = 2, 3 -> of the second.  A fragment is still
+//     one ds_read_b128 per lane (hi at logical position 2 (g & 1), lo one further);
+//   * the XOR swizzle becomes q ^ gray((row >> 2) & 3): with the four 16-lane groups of ds_read_b128
+//     ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32) every group then covers all 64 banks
+//     (the plain (row >> 2) & 3 of the 32 x 32 form is 2-way for this access);
+//   * a wave's 128 x 64 is 8 x 4 tiles of 16 x 16; the four column tiles take interleaved columns
+//     (tile y owns columns 4 j + y of the wave's 64), so a lane holds four adjacent output columns of
+//     four rows per row tile and stages them 16 bytes (fp32) or 8 + 8 bytes (hi, lo halves) at a time.
+__device__ __forceinline__ int Gray2(int c) { return c ^ (c >> 1); }
+__device__ __forceinline__ int WRowToCol16(int row) {
+  return (row & ~63) + 4 * (row & 15) + ((row >> 4) & 3);
+}
+__device__ __forceinline__ int SwzOff16(int row, int q) {
+  return row * 64 + ((q ^ Gray2((row >> 2) & 3)) << 4);
+}
+
+template <bool RELU, bool LAST, int TERMS>
+__global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the ring: 4 x 32 KiB = 2 pair slots
+  constexpr int kPairBytes = 2 * kHalfSlabBytes;
+
+  const int nblk = gridDim.x;                       // multiple of 8
+  const int b = blockIdx.x;
+  const int wg = (b % 8) * (nblk / 8) + b / 8;
+  const int super_m = (a.tiles_m + 3) / 4;
+  const int s = wg / 16, w = wg % 16;
+  const int tm = (s % super_m) * 4 + (w % 4);
+  const int tn = (s / super_m) * 4 + (w / 4);
+  if (tm >= a.tiles_m || tn >= a.tiles_n) return;
+  const int m0 = tm * kT, n0 = tn * kT;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;          // 2 x 4 waves
+  const int l15 = lane & 15, g = lane >> 4;
+
+  // ---- DMA role of this lane: as in the 32 x 32 form (pieces 2 wave, 2 wave + 1 of X and of W of
+  // every half-slab; a piece is 16 LDS rows, lane -> row lane >> 2, stored position lane & 3); the W rows
+  // of a piece are columns 4 apart
+  const char *sbase[2][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int row0 = (wave * 2 + p) * 16;
+    sbase[p][0] = reinterpret_cast<const char *>(a.X + (int64_t)(m0 + row0) * a.ldx);
+    sbase[p][1] = reinterpret_cast<const char *>(a.W + (int64_t)(n0 + WRowToCol16(row0)) * a.ldw);
+  }
+  const int lr = lane >> 2;
+  const int q = (lane & 3) ^ Gray2((lr >> 2) & 3);  // logical position landing at this lane's slot
+  const uint32_t voff[2] = {(uint32_t)(((int64_t)lr * a.ldx + q * 8) * sizeof(_Float16)),
+                            (uint32_t)(((int64_t)4 * lr * a.ldw + q * 8) * sizeof(_Float16))};
+  // piece 0..7 of pair P: half-slab 2 P + (piece >> 2), operand (piece >> 1) & 1, p = piece & 1
+  auto issue_piece = [&](int P, int piece) {
+    const int hs = 2 * P + (piece >> 2), op = (piece >> 1) & 1, p = piece & 1;
+    unsigned char *dst = smem + (hs & (kRingF16 - 1)) * kHalfSlabBytes + op * kOperandBytes + (wave * 2 + p) * 1024;
+    DmaScalarBase(reinterpret_cast<const float *>(dst), sbase[p][op] + hs * 64, voff[op]);
+  };
+
+  f32x4v acc[8][4];
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+
+  // fragment byte offsets inside a pair slot; row tile x / column tile y add 1024 x / 1024 y
+  const int half = (g >> 1) * kHalfSlabBytes;
+  const int aoff_h = half + SwzOff16(wm * 128 + l15, 2 * (g & 1));
+  const int aoff_l = half + SwzOff16(wm * 128 + l15, 2 * (g & 1) + 1);
+  const int boff_h = half + kOperandBytes + SwzOff16(wn * 64 + l15, 2 * (g & 1));
+  const int boff_l = half + kOperandBytes + SwzOff16(wn * 64 + l15, 2 * (g & 1) + 1);
+
+  const int npairs = a.K / 32;
+#pragma unroll
+  for (int piece = 0; piece < 8; ++piece) issue_piece(0, piece);
+  if (npairs > 1) {
+#pragma unroll
+    for (int piece = 0; piece < 8; ++piece) issue_piece(1, piece);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  f16x8 ah[2], al[2];          // A fragments: current row tile / next
+  f16x8 bh[2][4], bl[2][4];    // B fragments of the current / next step: [parity][y]
+  auto read_a = [&](const unsigned char *base, int x, f16x8 &h, f16x8 &l) {
+    h = *reinterpret_cast<const f16x8 *>(base + aoff_h + 1024 * x);
+    if (TERMS == 3) l = *reinterpret_cast<const f16x8 *>(base + aoff_l + 1024 * x);
+  };
+  auto read_b = [&](const unsigned char *base, int par, int y) {
+    bh[par][y] = *reinterpret_cast<const f16x8 *>(base + boff_h + 1024 * y);
+    if (TERMS == 3) bl[par][y] = *reinterpret_cast<const f16x8 *>(base + boff_l + 1024 * y);
+  };
+#pragma unroll
+  for (int y = 0; y < 4; ++y) read_b(smem, 0, y);
+  read_a(smem, 0, ah[0], al[0]);
+
+  // one term of the four column tiles of row tile x: consecutive MFMAs are independent
+  auto mfma_row = [&](int x, int cur, int par, int which) {
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      if (TERMS == 3 && which == 0) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur], bl[par][y], acc[x][y], 0, 0, 0);
+      if (TERMS == 3 && which == 1) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur], bh[par][y], acc[x][y], 0, 0, 0);
+      if (which == 2) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur], bh[par][y], acc[x][y], 0, 0, 0);
+    }
+  };
+  // ---- main loop over k32 steps P.  A step is eight groups (row tiles x) of twelve MFMAs; the A
+  // fragments of the next group are fetched under the current group's MFMAs.  Before the LAST group of
+  // step P: every fragment of step P is in registers (lgkmcnt(0)), pair P + 1 has landed (vmcnt(0): it
+  // is the only DMA in flight), barrier.  Behind it, under the MFMAs of that group and of the first
+  // groups of step P + 1: the B fragments and the first A fragments of step P + 1, and the eight DMA
+  // pieces of pair P + 2 into the slot step P has just released.
+  auto step = [&](int P, const int par) {             // par = P & 1, compile-time in the body
+    const unsigned char *base = smem + par * kPairBytes;
+    const unsigned char *next = smem + (par ^ 1) * kPairBytes;
+    const bool dma_late = P >= 1 && P + 1 < npairs;   // pieces 2..7 of pair P + 1 (its pieces 0, 1 went out in step P - 1)
+    const bool dma_head = P + 2 < npairs;             // pieces 0, 1 of pair P + 2
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const int cur = x & 1;
+      if (x == 7) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0): all of step P is in registers
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (TERMS == 3) {
+          mfma_row(x, cur, par, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          read_b(next, par ^ 1, 0);                   // stale on the last step, unused
+          read_b(next, par ^ 1, 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_row(x, cur, par, 1);
+          __builtin_amdgcn_sched_barrier(0);
+          read_b(next, par ^ 1, 2);
+          read_b(next, par ^ 1, 3);
+          read_a(next, 0, ah[cur ^ 1], al[cur ^ 1]);
+          if (dma_head) issue_piece(P + 2, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_row(x, cur, par, 2);
+          __builtin_amdgcn_sched_barrier(0);
+          if (dma_head) issue_piece(P + 2, 1);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          mfma_row(x, cur, par, 2);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int y = 0; y < 4; ++y) read_b(next, par ^ 1, y);
+          read_a(next, 0, ah[cur ^ 1], al[cur ^ 1]);
+          if (dma_head) { issue_piece(P + 2, 0); issue_piece(P + 2, 1); }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        read_a(base, x + 1, ah[cur ^ 1], al[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(x, cur, par, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (x < 3 && dma_late) issue_piece(P + 1, 2 + 2 * x);       // pieces 2, 4, 6
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(x, cur, par, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (x < 3 && dma_late) issue_piece(P + 1, 3 + 2 * x);       // pieces 3, 5, 7
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(x, cur, par, 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  for (int P = 0; P < npairs; P += 2) {
+    step(P, 0);
+    if (P + 1 < npairs) step(P + 1, 1);
+  }
+
+  // ---- epilogue: acc[x][y][r] = D[M0 + 16 x + 4 g + r][N0 + 4 l15 + y]; bias (nnet.cc:32-35), ReLU
+  // (nnet.cc:56-58).  Staged through this wave's own 2 x 8 KiB of the idle ring, 32 rows (two row tiles)
+  // at a time, as the rows will lie in memory -- 256 bytes per row: 64 fp32 logits, or 64 x (hi, lo)
+  // halves in chunks of 8 -- and written out 16 bytes per lane: one store instruction = four whole
+  // 256-byte row pieces.  No barrier: a wave reads back only what it wrote itself.
+  const int M0 = m0 + wm * 128, N0 = n0 + wn * 64 + 4 * l15;
+  const f32x4v bias = *reinterpret_cast<const f32x4v *>(a.bias + N0);
+  unsigned char *stage = smem + wave * (2 * 8192);
+  // byte offset of this lane's four columns in a staged row: fp32 quad, or the hi halves of chunk l15 / 2
+  const int quad_byte = LAST ? l15 * 16 : (l15 >> 1) * 32 + (l15 & 1) * 8;
+  unsigned char *out_rows = LAST ? reinterpret_cast<unsigned char *>(a.out_f32 + (int64_t)M0 * a.ldo + n0 + wn * 64)
+                                 : reinterpret_cast<unsigned char *>(a.out + (int64_t)M0 * a.ldo + 2 * (n0 + wn * 64));
+  const int64_t row_bytes = a.ldo * (LAST ? (int64_t)sizeof(float) : (int64_t)sizeof(_Float16));
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int xp = 0; xp < 4; ++xp) {
+    unsigned char *buf = stage + (xp & 1) * 8192;
+#pragma unroll
+    for (int xx = 0; xx < 2; ++xx) {
+      const int x = 2 * xp + xx;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * xx + 4 * g + r;
+        float v[4];
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+          v[y] = acc[x][y][r] + bias[y];
+          if (RELU) v[y] = v[y] < 0.0f ? 0.0f : v[y];
+        }
+        if (LAST) {
+          *reinterpret_cast<f32x4v *>(buf + row * 256 + quad_byte) = f32x4v{v[0], v[1], v[2], v[3]};
+        } else {
+          const SplitOut s0 = Split(v[0]), s1 = Split(v[1]), s2 = Split(v[2]), s3 = Split(v[3]);
+          *reinterpret_cast<f16x4 *>(buf + row * 256 + quad_byte) = f16x4{s0.hi, s1.hi, s2.hi, s3.hi};
+          *reinterpret_cast<f16x4 *>(buf + row * 256 + quad_byte + 16) = f16x4{s0.lo, s1.lo, s2.lo, s3.lo};
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                 // this wave's LDS writes are in
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                       // 8 KiB = 8 x (64 lanes x 16 bytes); lane -> row j*4 + lane/16
+      const int row = j * 4 + (lane >> 4);
+      const f32x4v v = *reinterpret_cast<const f32x4v *>(buf + row * 256 + (lane & 15) * 16);
+      *reinterpret_cast<f32x4v *>(out_rows + (int64_t)(32 * xp + row) * row_bytes + (lane & 15) * 16) = v;
+    }
+  }
+}
+
 // fp32 -> interleaved (hi, lo) fp16 rows.  in: element (r, c) at in[r * stride_r + c *
 // stride_c]; out row r starts at out + r * ld_out (halves); logical column c lives at
 // (c / 8) * 16 + c % 8 (hi) and 8 halves further (lo); columns cols..cols_pad-1 are zero.
@@ -379,14 +612,21 @@ void LaunchGemmF16(const GemmF16Args &a, hipStream_t stream) {
     hipGetDevice(&dev);
     std::lock_guard<std::mutex> g(mu);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-#define PK_SET_LDS(R, L, T) hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmF16Kernel<R, L, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+#define PK_SET_LDS(R, L, T) do { \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmF16Kernel<R, L, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmF16K32Kernel<R, L, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); } while (0)
       PK_SET_LDS(true, false, 3); PK_SET_LDS(false, false, 3); PK_SET_LDS(true, true, 3); PK_SET_LDS(false, true, 3);
       PK_SET_LDS(true, false, 1); PK_SET_LDS(false, false, 1); PK_SET_LDS(true, true, 1); PK_SET_LDS(false, true, 1);
 #undef PK_SET_LDS
       attr_set[dev] = true;
     }
   }
-#define PK_LAUNCH(R, L, T) hipLaunchKernelGGL((GemmF16Kernel<R, L, T>), grid, block, lds, stream, a)
+  // MFMA shape: 16x16x32 (k32 steps) by default; PK_MI355_F16_SHAPE=32 selects the round-2 32x32x16 form
+  // (k16 steps) for A/B measurements.  Same operands, layouts and tile; results differ in the last bits only
+  // (the k order of the fp32 accumulation), so one process must stay with one form: read once.
+  static const bool k32 = [] { const char *e = getenv("PK_MI355_F16_SHAPE"); return !(e && atoi(e) == 32); }();
+#define PK_LAUNCH(R, L, T) do { if (k32) hipLaunchKernelGGL((GemmF16K32Kernel<R, L, T>), grid, block, lds, stream, a); \
+                                else hipLaunchKernelGGL((GemmF16Kernel<R, L, T>), grid, block, lds, stream, a); } while (0)
   if (a.terms == 1) {
     if (a.out_f32) { if (a.relu) PK_LAUNCH(true, true, 1); else PK_LAUNCH(false, true, 1); }
     else { if (a.relu) PK_LAUNCH(true, false, 1); else PK_LAUNCH(false, false, 1); }

@@ -80,7 +80,7 @@ void LaunchGemm(const GemmArgs &a, hipStream_t stream);
 // ---------------------------------------------------------------- affine GEMM, f16x3 mode
 
 constexpr int kTileF16 = 256;   // block tile edge of the split-fp16 kernel
-constexpr int kBKF16 = 16;      // its k-step (one MFMA k16); K is padded to a multiple of this
+constexpr int kBKF16 = 32;      // its k-step (one v_mfma_f32_16x16x32_f16 = two k16 half-slabs); K is padded to a multiple of this
 
 // D[m][n] = sum_k X[m][k] * W[n][k] + bias[n] (ReLU), X and W carried as fp16 (hi, lo)
 // pairs, fp32 accumulation on the fp16 matrix cores (see gemm_f16.hip).
