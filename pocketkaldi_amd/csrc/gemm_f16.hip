@@ -472,8 +472,13 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a
   auto step = [&](int P, const int par) {             // par = P & 1, compile-time in the body
     const unsigned char *base = smem + par * kPairBytes;
     const unsigned char *next = smem + (par ^ 1) * kPairBytes;
-    const bool dma_late = P >= 1 && P + 1 < npairs;   // pieces 2..7 of pair P + 1 (its pieces 0, 1 went out in step P - 1)
-    const bool dma_head = P + 2 < npairs;             // pieces 0, 1 of pair P + 2
+    const bool dma_late = P >= 1 && P + 1 < npairs;   // the pieces of pair P + 1 that did not go out in step P - 1
+    const bool dma_head = P + 2 < npairs;             // the first pieces of pair P + 2
+    // Where the eight pieces go (A/B on one box, profiles/r03_f16_dma_schedule.txt): two behind the barrier, then
+    // ONE per group in groups 0-5 -- 500 / 475 TFLOP/s (two boxes) against 480 / 463 with two per group in groups
+    // 0-2: all eight waves of the CU issue in step, so pieces close together queue up in the texture path.
+    // One behind the barrier and one in each of groups 0-6 is no better, four behind the barrier is worse (462).
+    constexpr int kHead = 2;
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
       const int cur = x & 1;
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a
           __builtin_amdgcn_sched_barrier(0);
           mfma_row(x, cur, par, 2);
           __builtin_amdgcn_sched_barrier(0);
-          if (dma_head) issue_piece(P + 2, 1);
+          if (kHead == 2 && dma_head) issue_piece(P + 2, 1);
           __builtin_amdgcn_sched_barrier(0);
         } else {
           mfma_row(x, cur, par, 2);
@@ -505,7 +510,10 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a
 #pragma unroll
           for (int y = 0; y < 4; ++y) read_b(next, par ^ 1, y);
           read_a(next, 0, ah[cur ^ 1], al[cur ^ 1]);
-          if (dma_head) { issue_piece(P + 2, 0); issue_piece(P + 2, 1); }
+          if (dma_head) {
+#pragma unroll
+            for (int i = 0; i < kHead; ++i) issue_piece(P + 2, i);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
@@ -513,12 +521,9 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a
         __builtin_amdgcn_sched_barrier(0);
         mfma_row(x, cur, par, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (x < 3 && dma_late) issue_piece(P + 1, 2 + 2 * x);       // pieces 2, 4, 6
+        if (x < 6 && dma_late) issue_piece(P + 1, 2 + x);                         // pieces 2..7
         __builtin_amdgcn_sched_barrier(0);
         mfma_row(x, cur, par, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (x < 3 && dma_late) issue_piece(P + 1, 3 + 2 * x);       // pieces 3, 5, 7
-        __builtin_amdgcn_sched_barrier(0);
         mfma_row(x, cur, par, 2);
         __builtin_amdgcn_sched_barrier(0);
       }
