@@ -64,6 +64,39 @@ PK_EXPF_FN float ExpfRestated(float x, const uint64_t *tab) {
   return (float)y;
 }
 
+#ifdef __HIPCC__
+// The same function for a wavefront: the special cases (|x| >= 88, infinities, NaN) are tested once
+// for the whole wave and patched in with selects, so that the common case is straight-line code (as
+// separate per-lane branches hipcc moves the arithmetic out of line behind an exec-mask branch per
+// element).  Same results as ExpfRestated for every input: the arithmetic below is its main path,
+// and the selects are its early returns in the same priority.
+__device__ __forceinline__ float ExpfRestatedWave(float x, const uint64_t *tab) {
+  const uint32_t ix = __builtin_bit_cast(uint32_t, x);
+  const uint32_t abstop = (ix >> 20) & 0x7ff;
+  const double xd = (double)x;
+  const double z = 0x1.71547652b82fep+5 * xd;
+  double kd = z + 0x1.8p+52;
+  const uint64_t ki = __builtin_bit_cast(uint64_t, kd);
+  kd -= 0x1.8p+52;
+  const double r = __builtin_fma(0x1.71547652b82fep+5, xd, -kd);
+  const uint64_t t = tab[ki & 31] + (ki << 47);
+  const double s = __builtin_bit_cast(double, t);
+  const double q = __builtin_fma(0x1.c6af84b912394p-20, r, 0x1.ebfce50fac4f3p-13);
+  const double r2 = r * r;
+  double y = __builtin_fma(0x1.62e42ff0c52d6p-6, r, 1.0);
+  y = __builtin_fma(q, r2, y);
+  y = y * s;
+  float out = (float)y;
+  if (__builtin_amdgcn_ballot_w64(abstop >= 0x42b) != 0) {      // some lane of the wave is special
+    out = x < -0x1.9fe368p6f ? 0.0f : out;                        // underflow
+    out = x > 0x1.62e42ep6f ? __builtin_inff() : out;             // overflow
+    out = abstop >= 0x7f8 ? x + x : out;                          // +inf, NaN
+    out = ix == 0xff800000u ? 0.0f : out;                         // exp(-inf)
+  }
+  return out;
+}
+#endif
+
 }  // namespace pkmi
 
 #endif  // PK_EXPF_H_

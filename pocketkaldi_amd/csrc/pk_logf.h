@@ -67,6 +67,32 @@ PK_LOGF_FN float LogfRestated(float x, const double *tab) {
   return (float)y;
 }
 
+#ifdef __HIPCC__
+// The same function for a wavefront (see ExpfRestatedWave): x = 1, infinities and NaN are tested once
+// per wave and patched in with selects.
+__device__ __forceinline__ float LogfRestatedWave(float x, const double *tab) {
+  const uint32_t ix = __builtin_bit_cast(uint32_t, x);
+  const uint32_t tmp = ix - 0x3f330000u;
+  const int i = (tmp >> 19) & 15;
+  const int k = (int32_t)tmp >> 23;
+  const uint32_t iz = ix - (tmp & 0xff800000u);
+  const double invc = tab[2 * i], logc = tab[2 * i + 1];
+  const double z = (double)__builtin_bit_cast(float, iz);
+  const double r = __builtin_fma(z, invc, -1.0);
+  const double y0 = __builtin_fma((double)k, 0x1.62e42fefa39efp-1, logc);
+  const double r2 = r * r;
+  double y = __builtin_fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
+  y = __builtin_fma(-0x1.00ea348b88334p-2, r2, y);
+  y = __builtin_fma(y, r2, y0 + r);
+  float out = (float)y;
+  if (__builtin_amdgcn_ballot_w64(ix == 0x3f800000u || ix >= 0x7f800000u) != 0) {
+    out = ix == 0x3f800000u ? 0.0f : out;
+    out = ix >= 0x7f800000u ? x : out;
+  }
+  return out;
+}
+#endif
+
 }  // namespace pkmi
 
 #endif  // PK_LOGF_H_

@@ -4,6 +4,7 @@
 // (am.cc:106-112) and the acoustic scale (decodable.cc:15), plus the two layout
 // changes between feature-major panels and frame-major rows.  All HBM-bound.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "pk_expf.h"
 #include "pk_kernels.h"
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(64 * (kXProducers + 1)) void TailExactKernel(
         float ev[kPer];
         const bool live = t * kXCols + lane < n;
 #pragma unroll
-        for (int i = 0; i < kPer; ++i) ev[i] = live ? ExpfRestated(xv[i], s_expf) : 0.0f;   // + 0 leaves a sum as it is
+        for (int i = 0; i < kPer; ++i) ev[i] = live ? ExpfRestatedWave(xv[i], s_expf) : 0.0f;   // + 0 leaves a sum as it is
         if (t + 1 < ntiles) load_tile(t + 1);       // (requesting these before the arithmetic measured slower)
         float *dst = tile[t & 1] + (wv * kPer) * kXLd + lane;
 #pragma unroll
@@ -424,15 +425,117 @@ __global__ __launch_bounds__(64 * (kXProducers + 1)) void TailExactKernel(
     for (int i = 0; i < kPer; ++i) xv[i] = xrow[i][c];
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
-      float p = ExpfRestated(xv[i], s_expf);
+      float p = ExpfRestatedWave(xv[i], s_expf);
       p /= sum_r[i];
       if (MODE == kTailSoftmaxLoglik) {
         if (p < 1.0e-20f) p = 1.0e-20f;                               // am.cc:109
-        p = LogfRestated(p, s_logf);                                   // am.cc:110
+        p = LogfRestatedWave(p, s_logf);                                   // am.cc:110
         p = (p + -1.0f * lp) * scale;                                  // am.cc:111, decodable.cc:15
       }
       const int r = r0 + wv * kPer + i;
       if (r < rows) __builtin_nontemporal_store(p, out + (int64_t)r * ld_out + c);
+    }
+  }
+}
+
+// ---- the same arithmetic with e kept ON CHIP (rows of at most 3 008 columns: the 3 000-pdf model of the
+// BASELINE configs).  TailExactKernel reads every logit twice and exponentiates it twice because a
+// 64-row block of e does not fit in LDS; it fits in REGISTERS: a workgroup of sixteen waves owns 32
+// rows, wave w holds e of rows 2 w and 2 w + 1 (47 column tiles x 2 rows = 94 registers per lane;
+// lane = column inside a tile, so a wave streams its two rows through memory 256 contiguous bytes at
+// a time -- whole rows in order, the pattern HBM likes; the two-pass kernel touches 64 rows x 256 bytes
+// per step and reaches 3 TB/s).  For the column-order sum each tile of e also passes through LDS
+// (32 x 64, double-buffered) and ONE wave -- a different one per tile, so nobody falls behind -- adds
+// it to the running sums (lane = row; the sums travel from duty wave to duty wave through LDS; one
+// barrier per tile).  Then every wave finishes its own registers: e / sum, floor, logf, prior, scale --
+// one read of the logits, one expf, one write: 24 kB/frame instead of 36.
+constexpr int kRegTiles = 47;                          // 47 x 64 = 3 008 columns at most
+constexpr int kRegWaves = 16;
+constexpr int kRegRows = 2 * kRegWaves;                // rows per workgroup
+constexpr int kRegGroup = 1;                           // column tiles per barrier (2 measured no faster: 2.43 vs 2.33 ms)
+
+template <int MODE>
+__global__ __launch_bounds__(64 * kRegWaves) void TailExactRegKernel(
+    const float *__restrict__ in, int64_t ld_in, int rows, int n, const float *__restrict__ log_prior,
+    float scale, float *__restrict__ out, int64_t ld_out) {
+  __shared__ float tile[2][kRegGroup * kRegRows * kXLd];
+  __shared__ float s_sum[kRegRows];
+  __shared__ double s_logf[kLogfTableDoubles];
+  __shared__ uint64_t s_expf[kExpfTableWords];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (threadIdx.x < kLogfTableDoubles) s_logf[threadIdx.x] = kLogfTab[threadIdx.x];
+  if (threadIdx.x < kExpfTableWords) s_expf[threadIdx.x] = kExpfTab[threadIdx.x];
+  if (threadIdx.x < kRegRows) s_sum[threadIdx.x] = 0.0f;
+  const int r0 = blockIdx.x * kRegRows + 2 * wv;
+  // this wave's two rows (clamped: a partial block recomputes the last row, its stores are masked).
+  // Whole tiles are read: the launcher guarantees ld_in >= 64 ntiles (the logits rows are padded)
+  const float *x0 = in + (int64_t)(r0 < rows ? r0 : rows - 1) * ld_in + lane;
+  const float *x1 = in + (int64_t)(r0 + 1 < rows ? r0 + 1 : rows - 1) * ld_in + lane;
+  const int ntiles = (n + kXCols - 1) / kXCols;         // <= kRegTiles (the launcher checks)
+  __syncthreads();
+
+  float e0[kRegTiles], e1[kRegTiles];
+  float xa = __builtin_nontemporal_load(x0), xb = __builtin_nontemporal_load(x1);
+  // kRegGroup tiles per barrier (sixteen waves meet at every barrier: one per tile cost 15 %)
+#pragma unroll
+  for (int jg = 0; jg < kRegTiles; jg += kRegGroup) {
+    if (jg < ntiles) {                                  // uniform over the workgroup
+      float *buf = tile[(jg / kRegGroup) & 1];
+#pragma unroll
+      for (int jj = 0; jj < kRegGroup; ++jj) {
+        const int j = jg + jj;
+        if (j < kRegTiles && j < ntiles) {
+          const float ca = xa, cb = xb;
+          if (j + 1 < ntiles) {
+            xa = __builtin_nontemporal_load(x0 + (j + 1) * kXCols);
+            xb = __builtin_nontemporal_load(x1 + (j + 1) * kXCols);
+          }
+          const bool live = j * kXCols + lane < n;      // false only in the last tile's padding columns
+          const float ea = ExpfRestatedWave(ca, s_expf), eb = ExpfRestatedWave(cb, s_expf);
+          e0[j] = live ? ea : 0.0f;                     // + 0 leaves a sum as it is
+          e1[j] = live ? eb : 0.0f;
+          float *dst = buf + jj * (kRegRows * kXLd) + (2 * wv) * kXLd + lane;
+          dst[0] = e0[j];
+          dst[kXLd] = e1[j];
+        }
+      }
+      __syncthreads();
+      if (wv == ((jg / kRegGroup) & (kRegWaves - 1)) && lane < kRegRows) {   // this group's duty wave: lane = row
+        float s = s_sum[lane];
+#pragma unroll
+        for (int jj = 0; jj < kRegGroup; ++jj) {
+          if (jg + jj < kRegTiles && jg + jj < ntiles) {
+            const float *src = buf + jj * (kRegRows * kXLd) + lane * kXLd;
+#pragma unroll
+            for (int c = 0; c < kXCols; ++c) s += src[c];              // vector.cc:271
+          }
+        }
+        s_sum[lane] = s;
+      }
+    }
+  }
+  __syncthreads();
+  const float sum0 = s_sum[2 * wv], sum1 = s_sum[2 * wv + 1];
+  float *o0 = out + (int64_t)r0 * ld_out + lane, *o1 = o0 + ld_out;
+  const float *lpp = log_prior + lane;
+  const bool st0 = r0 < rows, st1 = r0 + 1 < rows;
+#pragma unroll
+  for (int j = 0; j < kRegTiles; ++j) {
+    if (j < ntiles) {
+      const bool live = j * kXCols + lane < n;
+      float p0 = e0[j] / sum0, p1 = e1[j] / sum1;                      // vector.cc:274-276
+      if (MODE == kTailSoftmaxLoglik) {
+        const float lp = live ? lpp[j * kXCols] : 0.0f;
+        if (p0 < 1.0e-20f) p0 = 1.0e-20f;                              // am.cc:109
+        if (p1 < 1.0e-20f) p1 = 1.0e-20f;
+        p0 = LogfRestatedWave(p0, s_logf);                             // am.cc:110
+        p1 = LogfRestatedWave(p1, s_logf);
+        p0 = (p0 + -1.0f * lp) * scale;                                // am.cc:111, decodable.cc:15
+        p1 = (p1 + -1.0f * lp) * scale;
+      }
+      if (live && st0) __builtin_nontemporal_store(p0, o0 + j * kXCols);
+      if (live && st1) __builtin_nontemporal_store(p1, o1 + j * kXCols);
     }
   }
 }
@@ -456,6 +559,16 @@ static void LaunchTailMode(const float *in, int64_t ld_in, int rows, int n, cons
 void LaunchTail(int mode, bool reference_exact, const float *in, int64_t ld_in, int rows, int n,
                 const float *log_prior, float scale, float *out, int64_t ld_out, hipStream_t stream) {
   if (rows <= 0 || n <= 0) return;
+  static const bool two_pass_only = [] { const char *e = getenv("PK_MI355_EXACT_TAIL_TWO_PASS"); return e && e[0] == '1'; }();
+  if (reference_exact && mode != kTailLoglik && n <= kRegTiles * kXCols && ld_in >= (n + kXCols - 1) / kXCols * kXCols &&
+      !two_pass_only) {
+    dim3 grid((rows + kRegRows - 1) / kRegRows), block(64 * kRegWaves);
+    if (mode == kTailSoftmaxProb)
+      hipLaunchKernelGGL((TailExactRegKernel<kTailSoftmaxProb>), grid, block, 0, stream, in, ld_in, rows, n, log_prior, scale, out, ld_out);
+    else
+      hipLaunchKernelGGL((TailExactRegKernel<kTailSoftmaxLoglik>), grid, block, 0, stream, in, ld_in, rows, n, log_prior, scale, out, ld_out);
+    return;
+  }
   if (reference_exact && mode != kTailLoglik) {
     dim3 grid((rows + kXRows - 1) / kXRows), block(64 * (kXProducers + 1));
     if (mode == kTailSoftmaxProb)
