@@ -626,10 +626,14 @@ void LaunchGemmF16(const GemmF16Args &a, hipStream_t stream) {
       attr_set[dev] = true;
     }
   }
-  // MFMA shape: 16x16x32 (k32 steps) by default; PK_MI355_F16_SHAPE=32 selects the round-2 32x32x16 form
-  // (k16 steps) for A/B measurements.  Same operands, layouts and tile; results differ in the last bits only
-  // (the k order of the fp32 accumulation), so one process must stay with one form: read once.
-  static const bool k32 = [] { const char *e = getenv("PK_MI355_F16_SHAPE"); return !(e && atoi(e) == 32); }();
+  // MFMA shape.  f16x3 (three MFMAs per product: bound by the matrix pipes and by the clock the chip holds) runs
+  // on 16x16x32, k32 steps: 486-506 against 447 TFLOP/s algorithmic on the wide model, profiles/r03_f16_shape_ab.txt.
+  // Plain fp16 (one MFMA per product: bound by the L2 -> LDS operand stream) keeps the round-2 32x32x16 form, whose
+  // k16 steps fetch three steps ahead instead of one: 675 against 597, profiles/r03_f16_plain_shape_ab.txt.
+  // PK_MI355_F16_SHAPE=16 / 32 forces one form for A/B measurements.  Same operands, layouts and tile; results
+  // differ in the last bits only (the k order of the fp32 accumulation), so the choice is fixed per process.
+  static const int forced = [] { const char *e = getenv("PK_MI355_F16_SHAPE"); return e ? atoi(e) : 0; }();
+  const bool k32 = forced == 16 || (forced != 32 && a.terms == 3);
 #define PK_LAUNCH(R, L, T) do { if (k32) hipLaunchKernelGGL((GemmF16K32Kernel<R, L, T>), grid, block, lds, stream, a); \
                                 else hipLaunchKernelGGL((GemmF16Kernel<R, L, T>), grid, block, lds, stream, a); } while (0)
   if (a.terms == 1) {
