@@ -376,6 +376,9 @@ template <bool RELU, bool LAST, int TERMS>
 __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the ring: 4 x 32 KiB = 2 pair slots
   constexpr int kPairBytes = 2 * kHalfSlabBytes;
+#ifdef PK_F16_STAMPS
+  const long long st_kernel = __builtin_amdgcn_s_memtime();
+#endif
 
   const int nblk = gridDim.x;                       // multiple of 8
   const int b = blockIdx.x;
@@ -454,6 +457,11 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a
   for (int y = 0; y < 4; ++y) read_b(smem, 0, y);
   read_a(smem, 0, ah[0], al[0]);
 
+#ifdef PK_F16_STAMPS
+  long long st_acc[4] = {0, 0, 0, 0};
+  long long st_last = __builtin_amdgcn_s_memtime();
+  const long long st_begin = st_last;
+#endif
   // one term of the four column tiles of row tile x: consecutive MFMAs are independent
   auto mfma_row = [&](int x, int cur, int par, int which) {
 #pragma unroll
@@ -483,9 +491,13 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a
     for (int x = 0; x < 8; ++x) {
       const int cur = x & 1;
       if (x == 7) {
+        PK_STAMP(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0): all of step P is in registers
+        PK_STAMP(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PK_STAMP(2);
         __builtin_amdgcn_s_barrier();
+        PK_STAMP(3);
         __builtin_amdgcn_sched_barrier(0);
         if (TERMS == 3) {
           mfma_row(x, cur, par, 0);
@@ -534,6 +546,9 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a
     if (P + 1 < npairs) step(P + 1, 1);
   }
 
+#ifdef PK_F16_STAMPS
+  const long long st_loop_end = __builtin_amdgcn_s_memtime();
+#endif
   // ---- epilogue: acc[x][y][r] = D[M0 + 16 x + 4 g + r][N0 + 4 l15 + y]; bias (nnet.cc:32-35), ReLU
   // (nnet.cc:56-58).  Staged through this wave's own 2 x 8 KiB of the idle ring, 32 rows (two row tiles)
   // at a time, as the rows will lie in memory -- 256 bytes per row: 64 fp32 logits, or 64 x (hi, lo)
@@ -581,6 +596,18 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a
       *reinterpret_cast<f32x4v *>(out_rows + (int64_t)(32 * xp + row) * row_bytes + (lane & 15) * 16) = v;
     }
   }
+#ifdef PK_F16_STAMPS
+  if (lane == 0 && blockIdx.x < 256) {
+    long long *o = pk_f16_stamps + (blockIdx.x * 8 + wave) * 8;
+    o[0] = st_loop_end - st_begin;                       // k loop, cycles
+    o[1] = st_acc[0];                                    // MFMA / issue segments (barrier release -> next lgkm wait)
+    o[2] = st_acc[1];                                    // lgkmcnt(0) wait
+    o[3] = st_acc[2];                                    // vmcnt wait
+    o[4] = st_acc[3];                                    // barrier wait
+    o[5] = st_begin - st_kernel;                         // prologue
+    o[6] = __builtin_amdgcn_s_memtime() - st_loop_end;   // epilogue (stores issued)
+  }
+#endif
 }
 
 // fp32 -> interleaved (hi, lo) fp16 rows.  in: element (r, c) at in[r * stride_r + c *

@@ -1,4 +1,4 @@
-// Developer probe: where a wave of GemmF16Kernel spends its k loop.  Builds the product kernel
+// Developer probe: where a wave of GemmF16K32Kernel (default) / GemmF16Kernel (PK_MI355_F16_SHAPE=32) spends its k loop.  Builds the product kernel
 // with s_memtime stamps around the three waits of a step (PK_F16_STAMPS; the product build has
 // none) and runs one hidden layer of the wide model: 65536 rows, K = N = 2048.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I../../pocketkaldi_amd/csrc f16_gemm_probe.hip -o f16_gemm_probe
@@ -37,7 +37,9 @@ int main() {
          2.0 * rows * K * N / (ms / reps) / 1e9, 6.0 * rows * K * N / (ms / reps) / 1e9);
   std::vector<long long> h(512 * 4 * 8);
   hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(pk_f16_stamps), h.size() * 8);
-  const int nsteps = K / 16;
+  const char *forced = getenv("PK_MI355_F16_SHAPE");
+  const bool k32 = !(forced && atoi(forced) == 32);
+  const int nsteps = k32 ? K / 32 : K / 16;
   double tot = 0, seg = 0, lg = 0, vm = 0, bar = 0, pro = 0, epi = 0; int n = 0;
   for (int b = 0; b < 512; ++b)
     for (int wv = 0; wv < 4; ++wv) {
@@ -45,7 +47,8 @@ int main() {
       if (o[0] <= 0) continue;
       tot += o[0]; seg += o[1]; lg += o[2]; vm += o[3]; bar += o[4]; pro += o[5]; epi += o[6]; ++n;
     }
-  printf("per wave: k loop %.0f cycles = %.1f per k16 step (ideal 2 x 768); of it: between waits %.1f %%, "
+  printf("%s\n", k32 ? "GemmF16K32Kernel (16x16x32, k32 steps; ideal 2 x 1536 cycles per step)" : "GemmF16Kernel (32x32x16, k16 steps; ideal 2 x 768 cycles per step)");
+  printf("per wave: k loop %.0f cycles = %.1f per step; of it: between waits %.1f %%, "
          "lgkm wait %.1f %%, vmcnt wait %.1f %%, barrier wait %.1f %%;  prologue %.0f cycles, epilogue %.0f cycles (%.1f %% of the tile)\n",
          tot / n, tot / n / nsteps, 100 * seg / tot, 100 * lg / tot, 100 * vm / tot, 100 * bar / tot, pro / n, epi / n,
          100 * (pro + epi) / (tot + pro + epi));
