@@ -407,15 +407,23 @@ int RunLayersF16(const pk_mi355_am *am, const ExecBufs &e, const _Float16 *x, in
     g.K = D.Kpad;
     g.bias = blob + D.b_off;
     g.relu = (i + 1 < nl && am->layers[i + 1].type == PK_NNET_RELU_LAYER) ? 1 : 0;
-    g.out_f32 = last ? e.a : nullptr;
-    g.out = last ? nullptr : e.h[buf];
-    g.ldo = last ? D.Npad : 2 * D.Npad;
+    // a NormalizeLayer behind this layer (nnet.cc:62-75; never behind the last one, Finalize checked): the GEMM
+    // leaves fp32 rows in `a` and NormalizeSplitKernel turns them into the next layer's (hi, lo) operand
+    const int after = i + 1 + g.relu;
+    const bool norm = after < nl && am->layers[after].type == PK_NNET_NORMALIZE_LAYER;
+    g.out_f32 = (last || norm) ? e.a : nullptr;
+    g.out = (last || norm) ? nullptr : e.h[buf];
+    g.ldo = (last || norm) ? D.Npad : 2 * D.Npad;
     g.tiles_m = rows_pad / kTileF16;
     g.tiles_n = D.Npad / kTileF16;
     g.terms = am->precision == PK_MI355_PRECISION_F16 ? 1 : 3;
     {
       Scoped t(timer, PK_MI355_K_GEMM, stream);
       LaunchGemmF16(g, stream);
+    }
+    if (norm) {
+      Scoped t(timer, PK_MI355_K_OTHER, stream);
+      LaunchNormalizeSplitF16(e.a, D.Npad, rows_pad, D.N, D.Npad, e.h[buf], 2 * D.Npad, stream);
     }
     x = e.h[buf]; ldx = 2 * D.Npad;
     out_ld = D.Npad;
@@ -712,17 +720,21 @@ int pk_mi355_am_finalize(pk_mi355_am_t *am, const float *prior, int num_pdfs, in
   // dimension chain
   const bool f16 = IsF16(am->precision);
   if (f16) {
-    // the split-fp16 path covers the BASELINE model family: (Linear [ReLU])+ [Softmax]
+    // the split-fp16 path covers (Linear [ReLU] [Normalize])+ [Softmax]: the BASELINE model family and the
+    // relu + renormalize stacks tool/convert_am.py writes (a Normalize must be followed by another Linear)
     const int nl = (int)am->layers.size();
     bool ok = nl > 0 && am->layers[0].type == PK_NNET_LINEAR_LAYER;
     for (int i = 0; ok && i < nl; ++i) {
       const int t = am->layers[i].type;
       if (t == PK_NNET_RELU_LAYER) ok = i > 0 && am->layers[i - 1].type == PK_NNET_LINEAR_LAYER;
+      else if (t == PK_NNET_NORMALIZE_LAYER)
+        ok = i > 0 && i + 1 < nl && am->layers[i + 1].type == PK_NNET_LINEAR_LAYER &&
+             (am->layers[i - 1].type == PK_NNET_LINEAR_LAYER ||
+              (am->layers[i - 1].type == PK_NNET_RELU_LAYER && i >= 2 && am->layers[i - 2].type == PK_NNET_LINEAR_LAYER));
       else if (t == PK_NNET_SOFTMAX_LAYER) ok = (i == nl - 1);
       else if (t != PK_NNET_LINEAR_LAYER) ok = false;
     }
-    if (ok && am->layers.back().type == PK_NNET_RELU_LAYER && nl >= 2) ok = true;
-    if (!ok) return Fail(PK_MI355_E_INVALID, "f16x3 / f16 precision supports (Linear [ReLU])+ [Softmax] networks only");
+    if (!ok) return Fail(PK_MI355_E_INVALID, "f16x3 / f16 precision supports (Linear [ReLU] [Normalize])+ [Softmax] networks only");
   }
   int first_in = 0, dim = 0;
   am->lin.clear();

@@ -673,6 +673,53 @@ void LaunchGemmF16(const GemmF16Args &a, hipStream_t stream) {
 #undef PK_LAUNCH
 }
 
+// NormalizeLayer (nnet.cc:62-75) between two f16x3 affine layers: fp32 rows in (what the GEMM wrote with
+// its out_f32 epilogue), y = x * float(sqrt(D / sum x^2)), interleaved (hi, lo) rows out -- the next layer's
+// operand.  One wave per row, a lane owns chunks of 8 columns (one 16-byte hi store + one lo store each);
+// the row is read twice (the second time out of L2).  The sum is a tree, not the reference's sequential
+// float sum: this mode is not bit-exact anyway (1e-4 contract).  Columns n .. npad - 1 are written as zeros.
+namespace {
+__global__ __launch_bounds__(256) void NormalizeSplitKernel(const float *__restrict__ in, int64_t ld_in, int rows, int n,
+                                                            int npad, _Float16 *__restrict__ out, int64_t ld_out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float *x = in + (int64_t)row * ld_in;
+  float ssq = 0.0f;
+  for (int c = lane * 8; c < npad; c += 64 * 8) {
+    const f32x4v a = *reinterpret_cast<const f32x4v *>(x + c), b = *reinterpret_cast<const f32x4v *>(x + c + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (c + e < n) ssq += a[e] * a[e];
+      if (c + 4 + e < n) ssq += b[e] * b[e];
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) ssq += __shfl_xor(ssq, m);
+  const float scale = static_cast<float>(sqrt(static_cast<double>(n) / static_cast<double>(ssq)));   // nnet.cc:70-72
+  _Float16 *o = out + (int64_t)row * ld_out;
+  for (int c = lane * 8; c < npad; c += 64 * 8) {
+    const f32x4v a = *reinterpret_cast<const f32x4v *>(x + c), b = *reinterpret_cast<const f32x4v *>(x + c + 4);
+    f16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = e < 4 ? a[e] : b[e - 4];
+      const SplitOut sp = Split(c + e < n ? v * scale : 0.0f);
+      hi[e] = sp.hi;
+      lo[e] = sp.lo;
+    }
+    *reinterpret_cast<f16x8 *>(o + 2 * c) = hi;
+    *reinterpret_cast<f16x8 *>(o + 2 * c + 8) = lo;
+  }
+}
+}  // namespace
+
+void LaunchNormalizeSplitF16(const float *in, int64_t ld_in, int rows, int n, int npad, _Float16 *out, int64_t ld_out,
+                             hipStream_t stream) {
+  if (rows <= 0 || n <= 0) return;
+  hipLaunchKernelGGL(NormalizeSplitKernel, dim3((rows + 3) / 4), dim3(256), 0, stream, in, ld_in, rows, n, npad, out, ld_out);
+}
+
 void LaunchSplitF16(const float *in, int64_t stride_r, int64_t stride_c, int rows, int cols,
                     int cols_pad, _Float16 *out, int64_t ld_out, hipStream_t stream) {
   if (rows <= 0 || cols_pad <= 0) return;

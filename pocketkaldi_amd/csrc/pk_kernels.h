@@ -107,6 +107,10 @@ void LaunchGemmF16(const GemmF16Args &a, hipStream_t stream);
 // fp32 -> interleaved (hi, lo) fp16 rows: element (r, c) read at in[r * stride_r + c *
 // stride_c]; row r of the output starts at out + r * ld_out (halves); columns
 // cols..cols_pad-1 are zero-filled (cols_pad multiple of 8).
+// NormalizeLayer (nnet.cc:62-75) between two f16x3 layers: fp32 rows [rows][ld_in] -> normalized interleaved
+// (hi, lo) rows [rows][ld_out halves]; columns n..npad-1 zero (npad a multiple of 8, <= ld_in).
+void LaunchNormalizeSplitF16(const float *in, int64_t ld_in, int rows, int n, int npad, _Float16 *out, int64_t ld_out,
+                             hipStream_t stream);
 void LaunchSplitF16(const float *in, int64_t stride_r, int64_t stride_c, int rows, int cols,
                     int cols_pad, _Float16 *out, int64_t ld_out, hipStream_t stream);
 

@@ -421,11 +421,34 @@ def test_f16x3_ragged_batch_and_chunking(monkeypatch):
 
 
 def test_f16x3_rejects_unsupported_layer_patterns():
+    eye = ("linear", np.eye(8, dtype=np.float32), np.zeros(8, np.float32))
+    with pytest.raises(pk.PkError):                 # a Normalize must sit between two affine layers
+        pk.AcousticModel([eye, ("normalize",)], num_pdfs=8, precision="f16x3")
     with pytest.raises(pk.PkError):
-        pk.AcousticModel([("linear", np.eye(8, dtype=np.float32), np.zeros(8, np.float32)), ("normalize",)],
-                         num_pdfs=8, precision="f16x3")
+        pk.AcousticModel([eye, ("normalize",), ("normalize",), eye], num_pdfs=8, precision="f16x3")
     with pytest.raises(pk.PkError):
         pk.AcousticModel([("softmax",)], num_pdfs=8, precision="f16x3")
+    pk.AcousticModel([eye, ("relu",), ("normalize",), eye, ("softmax",)], num_pdfs=8, precision="f16x3")    # accepted
+
+
+def test_f16x3_normalize_layers_batch_path_within_contract():
+    """The relu + renormalize stack through the BATCH scorer in f16x3 (NormalizeSplitKernel between the GEMMs):
+    ragged utterances, every one inside the contract against the oracle, and measured an order below."""
+    rng = np.random.default_rng(41)
+    layers, prior = _random_net(rng, [440, 384, 520, 300, 700], normalize_p=1.0)
+    assert [l[0] for l in layers].count("normalize") == 3
+    g = synth.global_cmvn_stats()
+    waves = [synth.utterance(300 + u, s) for u, s in enumerate([1.3, 0.05, 4.0, 2.2])]
+    am = pk.AcousticModel(layers, prior, 5, 5, precision="f16x3")
+    bs = pk.BatchScorer(am, g, len(waves), sum(len(w) for w in waves))
+    bs.set_waves(waves)
+    bs.score(0.1)
+    nn = O.Nnet(layers)
+    for u, w in enumerate(waves):
+        ref = nn.am_compute(O.cmvn(g, O.Fbank().compute(w)), prior, 5, 5, 0.1)
+        got = bs.fetch(u).log_prob()
+        assert_loglik_close(got, ref)
+        assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)) < 2e-5
 
 
 def test_device_side_loglikelihood_gather():
@@ -1037,6 +1060,12 @@ def test_fuzz_f16x3_decodable_within_contract(seed):
         layers.append(("linear", (rng.standard_normal((dims[i + 1], dims[i])) * np.sqrt(2.0 / dims[i])).astype(np.float32),
                        (rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32)))
         layers.append(("relu",) if i < len(dims) - 2 else ("softmax",))
+        # round 3: NormalizeLayer (nnet.cc:62-75) between two affine layers -- the relu + renormalize stacks
+        # tool/convert_am.py writes -- with or without the ReLU in front of it
+        if i < len(dims) - 2 and rng.random() < 0.4:
+            if rng.random() < 0.25:
+                layers.pop()
+            layers.append(("normalize",))
     prior = rng.uniform(0.5, 1.5, dims[-1])
     prior = (prior / prior.sum()).astype(np.float32)
     T = int(rng.choice([1, 3, 255, 256, 257, 1000, 4500]))

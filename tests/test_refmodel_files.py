@@ -51,10 +51,7 @@ def test_pk_load_reads_the_reference_written_model(precision):
     """pk_mi355_load (pk_load's share, pocketkaldi.cc:72-144) on the reference-written files ==
     the model built in memory from the text, bit for bit; and == the oracle on the same features."""
     layers, prior, L, R, tid2pdf, cmvn41 = load_text_model()
-    if precision == "f16x3":        # the model has a Normalize layer: f16x3 covers (Linear [ReLU])+ [Softmax] only
-        with pytest.raises(pk.PkError, match="precision supports"):
-            pk.AcousticModel.load(os.path.join(DIR, "refmodel.conf"), precision=precision)
-        return
+    # (the model has a Normalize layer: f16x3 covers (Linear [ReLU] [Normalize])+ [Softmax] since round 3)
     am_file, stats = pk.AcousticModel.load(os.path.join(DIR, "refmodel.conf"), precision=precision)
     am_mem = pk.AcousticModel(layers, prior, L, R, tid2pdf, precision=precision)
     assert bits_equal(stats, cmvn41)
