@@ -134,7 +134,9 @@ int pk_mi355_am_add_layer(pk_mi355_am_t *am, int layer_type);
  *   F16X3 : every fp32 operand carried as an fp16 (hi, lo) pair, three fp16 MFMAs per
  *           product, fp32 accumulation: ~1e-6 relative on log-likelihoods (inside the
  *           1e-4 contract, not bit-exact), several times faster.  Supports
- *           (Linear [ReLU] [Normalize])+ [Softmax] networks; |values| above 65504 saturate.
+ *           (Linear [ReLU] [Normalize])+ [Softmax] networks; |values| above 65504 saturate, and so
+ *           does NaN: where the reference's NormalizeLayer turns an all-zero row into NaN (0 * inf,
+ *           nnet.cc:62-75) this mode keeps the row zero.  F32 reproduces the NaN.
  *   F16   : plain fp16 operands (the hi halves only), ONE fp16 MFMA per product, fp32 accumulation --
  *           the throughput ceiling of the fp16 matrix cores at a STATED, looser tolerance: ~1e-3
  *           relative on log-likelihoods, OUTSIDE the 1e-4 contract of the path (SURVEY section 7,

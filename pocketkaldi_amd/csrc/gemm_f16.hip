@@ -696,7 +696,9 @@ __global__ __launch_bounds__(256) void NormalizeSplitKernel(const float *__restr
   }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) ssq += __shfl_xor(ssq, m);
-  const float scale = static_cast<float>(sqrt(static_cast<double>(n) / static_cast<double>(ssq)));   // nnet.cc:70-72
+  // nnet.cc:70-72.  An all-zero row makes the reference produce NaN (0 * inf, no epsilon: SURVEY a17); this mode's
+  // operands cannot carry NaN (the split saturates, include/pk_mi355.h), so such a row stays all-zero here
+  const float scale = ssq > 0.0f ? static_cast<float>(sqrt(static_cast<double>(n) / static_cast<double>(ssq))) : 0.0f;
   _Float16 *o = out + (int64_t)row * ld_out;
   for (int c = lane * 8; c < npad; c += 64 * 8) {
     const f32x4v a = *reinterpret_cast<const f32x4v *>(x + c), b = *reinterpret_cast<const f32x4v *>(x + c + 4);

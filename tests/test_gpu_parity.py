@@ -1072,8 +1072,15 @@ def test_fuzz_f16x3_decodable_within_contract(seed):
     feats = rng.standard_normal((T, D)).astype(np.float32)
     got = pk.Decodable(pk.AcousticModel(layers, prior, L, R, precision="f16x3"), 0.1, feats).log_prob()
     ref = O.Nnet(layers).am_compute(feats, prior, L, R, 0.1)
+    # a frame whose activations are all zero in front of a Normalize is NaN in the reference (0 * inf, nnet.cc:62-75;
+    # seeds 20266, 20306, 21638 of the round-3 soak: tiny random nets); f16x3 operands saturate instead of carrying
+    # NaN (include/pk_mi355.h), so those frames are outside this mode's contract -- and finite here
+    bad = np.isnan(ref).any(axis=1)
+    assert np.all(np.isfinite(got))
+    assert bad.mean() < 0.5
+    got, ref = got[~bad], ref[~bad]
     assert_loglik_close(got, ref)
-    assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)) < 2e-5, "dims %s L %d R %d T %d" % (dims, L, R, T)
+    assert got.size == 0 or np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)) < 2e-5, "dims %s L %d R %d T %d" % (dims, L, R, T)
 
 
 def _random_net(rng, dims, normalize_p=0.0):
