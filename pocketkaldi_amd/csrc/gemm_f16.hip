@@ -311,9 +311,9 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
       float v0 = acc[x][0][r] + bias[0], v1 = acc[x][1][r] + bias[1];
-      if (RELU) {
-        v0 = v0 < 0.0f ? 0.0f : v0;
-        v1 = v1 < 0.0f ? 0.0f : v1;
+      if (RELU) {               // one v_max_f32 (folds into the split's clamp); NaN / -0.0 are not carried by this mode
+        v0 = fmaxf(v0, 0.0f);
+        v1 = fmaxf(v1, 0.0f);
       }
       if (LAST) {
         *reinterpret_cast<f32x2 *>(buf + row * 256 + pair_byte) = f32x2{v0, v1};
@@ -563,6 +563,19 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a
                                  : reinterpret_cast<unsigned char *>(a.out + (int64_t)M0 * a.ldo + 2 * (n0 + wn * 64));
   const int64_t row_bytes = a.ldo * (LAST ? (int64_t)sizeof(float) : (int64_t)sizeof(_Float16));
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  // bias and ReLU on whole accumulator vectors: the add pairs up (v_pk_add_f32), the ReLU is one v_max_f32.  (max
+  // instead of the reference's x < 0 ? 0 : x differs for NaN and -0.0 only, which this mode's saturating split
+  // does not carry anyway.)
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      acc[x][y] += f32x4v{bias[y], bias[y], bias[y], bias[y]};
+      if (RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[x][y][r] = fmaxf(acc[x][y][r], 0.0f);
+      }
+    }
 #pragma unroll
   for (int xp = 0; xp < 4; ++xp) {
     unsigned char *buf = stage + (xp & 1) * 8192;
@@ -574,10 +587,7 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a
         const int row = 16 * xx + 4 * g + r;
         float v[4];
 #pragma unroll
-        for (int y = 0; y < 4; ++y) {
-          v[y] = acc[x][y][r] + bias[y];
-          if (RELU) v[y] = v[y] < 0.0f ? 0.0f : v[y];
-        }
+        for (int y = 0; y < 4; ++y) v[y] = acc[x][y][r];
         if (LAST) {
           *reinterpret_cast<f32x4v *>(buf + row * 256 + quad_byte) = f32x4v{v[0], v[1], v[2], v[3]};
         } else {
