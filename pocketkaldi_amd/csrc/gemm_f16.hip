@@ -6,9 +6,12 @@
 //
 //   D[m][n] = sum_k Xhi Whi + Xhi Wlo + Xlo Whi          (Xlo Wlo ~ 2^-22, dropped)
 //
-// three v_mfma_f32_32x32x16_f16 per 32 x 32 x 16 block into ONE fp32 accumulator
-// (fp16 products are exact in fp32; the cross terms sit 11 bits below the main term
-// and fit the accumulator).  Measured error vs the fp32 reference chain is ~1e-6
+// three fp16 MFMAs per block into ONE fp32 accumulator (fp16 products are exact in fp32; the
+// cross terms sit 11 bits below the main term and fit the accumulator).  Two kernels share the
+// layouts, the tile and the LDS-DMA ring described here:
+//   GemmF16K32Kernel  v_mfma_f32_16x16x32_f16, k32 steps -- what f16x3 runs on (round 3; further down)
+//   GemmF16Kernel     v_mfma_f32_32x32x16_f16, k16 steps -- the round-2 form, kept for the plain-fp16
+//                     mode (one MFMA per product), which is bound by the operand stream, not by the clock.  Measured error vs the fp32 reference chain is ~1e-6
 // relative on log-likelihoods -- inside the 1e-4 contract, not bit-exact.  Range: fp16
 // saturates at 65504; the split clamps instead of overflowing.
 //
