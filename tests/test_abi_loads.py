@@ -156,3 +156,71 @@ def test_broadcast_entry_reports_misuse_without_gpu():
         assert L.pk_mi355_am_broadcast(None, None, 0, None) != 0
     finally:
         L.pk_mi355_am_destroy(am)
+
+
+def test_readers_survive_mutated_files(tmp_path):
+    """The host-side readers parse files a caller hands them (pcm_reader.cc:45-220, nnet.cc:80-147, vector.cc:393-425):
+    truncated, bit-flipped, length-field-poisoned and over-long variants of the reference-written model files and of the
+    reference's WAV must end in an error code (or a valid parse), never in a crash or an exception across the C ABI.
+    (No GPU here: a model that parses stops at PK_MI355_E_DEVICE when it would be uploaded.)"""
+    import ctypes as C
+    import random
+    L = pk.lib()
+    D = os.path.join(GOLDEN, "refmodel")
+    names = ["refmodel.nnet", "refmodel.prior", "refmodel_tid2pdf.bin", "refmodel_cmvn.bin"]
+    orig = {n: open(os.path.join(D, n), "rb").read() for n in names}
+    conf = ("cmvn_stats = refmodel_cmvn.bin\nnnet = refmodel.nnet\nprior = refmodel.prior\nleft_context = 2\n"
+            "right_context = 1\nnum_pdfs = 18\ntid2pdf = refmodel_tid2pdf.bin\n")
+    (tmp_path / "m.conf").write_text(conf)
+    rng = random.Random(7)
+
+    def mutate(data):
+        data = bytearray(data)
+        mode = rng.randrange(4)
+        if mode == 0:
+            return bytes(data[:rng.randrange(len(data))])
+        if mode == 1:
+            for _ in range(rng.randrange(1, 6)):
+                data[rng.randrange(len(data))] = rng.randrange(256)
+        elif mode == 2:
+            pos = rng.randrange(0, max(1, len(data) - 4))
+            data[pos:pos + 4] = rng.choice([0x7FFFFFFF, 0xFFFFFFFF, 0x80000000, 0, 1 << 30]).to_bytes(4, "little")
+        else:
+            data += bytes(rng.randrange(1, 64))
+        return bytes(data)
+
+    codes = set()
+    for _ in range(400):
+        for n in names:
+            (tmp_path / n).write_bytes(orig[n])
+        victim = rng.choice(names)
+        (tmp_path / victim).write_bytes(mutate(orig[victim]))
+        h, stats = C.c_void_p(), np.zeros(41, np.float32)
+        rc = L.pk_mi355_load(str(tmp_path / "m.conf").encode(), 0, C.byref(h), stats.ctypes.data_as(C.POINTER(C.c_float)))
+        codes.add(rc)
+        if rc == 0:
+            L.pk_mi355_am_destroy(h)
+    assert codes <= {0, -1, -2, -3} and -3 in codes
+
+    wav = open(os.path.join(GOLDEN, "en-us-hello.wav"), "rb").read()
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    codes = set()
+    for _ in range(400):
+        data = bytearray(wav)
+        mode = rng.randrange(3)
+        if mode == 0:
+            data = data[:rng.randrange(len(data))]
+        elif mode == 1:
+            for _ in range(rng.randrange(1, 6)):
+                data[rng.randrange(0, 64)] = rng.randrange(256)
+        else:
+            pos = rng.randrange(0, 40)
+            data[pos:pos + 4] = rng.choice([0x7FFFFFFF, 0xFFFFFFFF, 0x80000000, 0]).to_bytes(4, "little")
+        (tmp_path / "x.wav").write_bytes(bytes(data))
+        v = pk.pk_vector_t(0, None)
+        rc = L.pk_mi355_16kpcm_read(str(tmp_path / "x.wav").encode(), C.byref(v))
+        codes.add(rc)
+        if v.data:
+            libc.free(C.cast(v.data, C.c_void_p))
+    assert codes <= {0, -3} and -3 in codes
