@@ -83,7 +83,8 @@ enum {
   PK_MI355_E_INVALID = -1,   /* bad argument / shape mismatch            */
   PK_MI355_E_DEVICE = -2,    /* HIP runtime failure or no gfx950 device  */
   PK_MI355_E_IO = -3,        /* file missing or corrupted                */
-  PK_MI355_E_STATE = -4      /* call order (e.g. model not finalized)    */
+  PK_MI355_E_STATE = -4,     /* call order (e.g. model not finalized)    */
+  PK_MI355_E_RANGE = -5      /* f16x3 / f16: an operand left the fp16 split's range (results withheld) */
 };
 
 const char *pk_mi355_last_error(void);
@@ -134,8 +135,18 @@ int pk_mi355_am_add_layer(pk_mi355_am_t *am, int layer_type);
  *   F16X3 : every fp32 operand carried as an fp16 (hi, lo) pair, three fp16 MFMAs per
  *           product, fp32 accumulation: ~1e-6 relative on log-likelihoods (inside the
  *           1e-4 contract, not bit-exact), several times faster.  Supports
- *           (Linear [ReLU] [Normalize])+ [Softmax] networks; |values| above 65504 saturate, and so
- *           does NaN: where the reference's NormalizeLayer turns an all-zero row into NaN (0 * inf,
+ *           (Linear [ReLU] [Normalize])+ [Softmax] networks.
+ *           RANGE (round 4).  fp16 holds 2^-24 .. 65504 and the lo half sits 2^-12 below its value, so the
+ *           accuracy above holds only while operands sit well inside that window.  Weights: every affine
+ *           layer's W is multiplied by an exact power of two at finalize (max |W| -> [2^13, 2^14)) and the
+ *           GEMM's epilogue divides it out again -- automatic, any training scale.  Activations: the operand
+ *           of every affine layer carries an exponent too (x * 2^e is what is split; default 0, set by
+ *           pk_mi355_am_calibrate / pk_mi355_am_set_input_exponents), and every call CHECKS what it wrote:
+ *           an operand that reached the clamp at 65504, or whose largest magnitude stayed below 2^-5
+ *           (every lo half subnormal), fails the call with PK_MI355_E_RANGE -- pk_decodable_init leaves
+ *           log_prob empty, the batch calls return the code (score with sync, synchronize, fetch, fetch_all)
+ *           -- and pk_mi355_last_error() names the layer.  Nothing out of range is returned quietly.
+ *           NaN is not carried: where the reference's NormalizeLayer turns an all-zero row into NaN (0 * inf,
  *           nnet.cc:62-75) this mode keeps the row zero.  F32 reproduces the NaN.
  *   F16   : plain fp16 operands (the hi halves only), ONE fp16 MFMA per product, fp32 accumulation --
  *           the throughput ceiling of the fp16 matrix cores at a STATED, looser tolerance: ~1e-3
@@ -144,6 +155,19 @@ int pk_mi355_am_add_layer(pk_mi355_am_t *am, int layer_type);
 enum { PK_MI355_PRECISION_F32 = 0, PK_MI355_PRECISION_F16X3 = 1, PK_MI355_PRECISION_F16 = 2 };
 int pk_mi355_am_set_precision(pk_mi355_am_t *am, int precision);
 int pk_mi355_am_precision(const pk_mi355_am_t *am);
+
+/* F16X3 / F16: the operand exponents (no-ops returning 0 exponents / success in F32).
+ * get: w_exp[l] = the power of two the weights of affine layer l were multiplied by at finalize, x_exp[l] = the
+ *      exponent of that layer's input operand; returns the number of affine layers (<= capacity) or a negative code.
+ * set_input_exponents: count == number of affine layers, each in [-30, 30].
+ * calibrate: feats as for pk_decodable_init (CMVN'd features, {ncol = T, nrow = feat_dim}).  Runs the network on
+ *      them, reads every operand's largest magnitude back from the device and sets its exponent so that it lands in
+ *      [2^10, 2^11) (32 x headroom to the clamp), layer by layer until all are in band.  The exponents live in the
+ *      weight blob: pk_mi355_am_broadcast carries the root's calibration to every rank.  Calibrate while nothing
+ *      is being scored with the model.  pk_mi355_batch_calibrate (below) does the same from the batch's waves. */
+int pk_mi355_am_get_exponents(pk_mi355_am_t *am, int32_t *w_exp, int32_t *x_exp, int capacity);
+int pk_mi355_am_set_input_exponents(pk_mi355_am_t *am, const int32_t *x_exp, int count);
+int pk_mi355_am_calibrate(pk_mi355_am_t *am, const pk_matrix_t *feats);
 
 /* Arithmetic of the softmax / log-likelihood tail (any time; default STABLE).
  *   STABLE    : log-softmax with the row maximum subtracted -- finite for any logits, within
@@ -257,6 +281,9 @@ int pk_mi355_batch_set_waves_device(pk_mi355_batch_t *b, const float *d_samples,
  * Asynchronous on the batch's stream unless sync != 0.  Results stay in HBM.     */
 int pk_mi355_batch_score(pk_mi355_batch_t *b, float prob_scale, int sync);
 int pk_mi355_batch_synchronize(pk_mi355_batch_t *b);
+/* F16X3 / F16: pk_mi355_am_calibrate on the utterances currently set (front-end included).  Overwrites the
+ * batch's results; score again afterwards.                                                               */
+int pk_mi355_batch_calibrate(pk_mi355_batch_t *b);
 
 int pk_mi355_batch_num_utts(const pk_mi355_batch_t *b);
 int pk_mi355_batch_num_frames(const pk_mi355_batch_t *b, int utt);

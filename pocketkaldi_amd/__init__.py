@@ -68,6 +68,7 @@ EXPORTS = [
     "pk_mi355_batch_stream", "pk_mi355_batch_enable_timing", "pk_mi355_batch_get_timing",
     "pk_mi355_am_flops_per_frame", "pk_mi355_16kpcm_read", "pk_mi355_process_acoustic",
     "pk_mi355_device_count", "pk_mi355_version",
+    "pk_mi355_am_get_exponents", "pk_mi355_am_set_input_exponents", "pk_mi355_am_calibrate", "pk_mi355_batch_calibrate",
 ]
 
 
@@ -174,6 +175,10 @@ def lib():
     L.pk_mi355_16kpcm_read.argtypes = [C.c_char_p, C.POINTER(pk_vector_t)]
     L.pk_mi355_process_acoustic.argtypes = [C.c_void_p, C.POINTER(pk_vector_t), C.POINTER(pk_vector_t), C.c_float,
                                             C.POINTER(pk_decodable_t), C.c_int]
+    L.pk_mi355_am_get_exponents.argtypes = [C.c_void_p, i32p, i32p, C.c_int]
+    L.pk_mi355_am_set_input_exponents.argtypes = [C.c_void_p, i32p, C.c_int]
+    L.pk_mi355_am_calibrate.argtypes = [C.c_void_p, C.POINTER(pk_matrix_t)]
+    L.pk_mi355_batch_calibrate.argtypes = [C.c_void_p]
     _lib = L
     return L
 
@@ -362,6 +367,27 @@ class AcousticModel:
         _check(lib().pk_mi355_am_broadcast_from(self._h, None if src is None else src.handle, C.c_void_p(rccl_comm),
                                                 int(root), None if stream is None else C.c_void_p(stream)))
 
+    def exponents(self):
+        """f16x3 / f16: (w_exp, x_exp) per affine layer -- the exact power-of-two operand scalings."""
+        w = np.zeros(64, dtype=np.int32)
+        x = np.zeros(64, dtype=np.int32)
+        n = lib().pk_mi355_am_get_exponents(self._h, w.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            x.ctypes.data_as(C.POINTER(C.c_int32)), 64)
+        if n < 0:
+            _check(n)
+        return w[:n].copy(), x[:n].copy()
+
+    def set_input_exponents(self, x_exp):
+        x = np.ascontiguousarray(x_exp, dtype=np.int32)
+        _check(lib().pk_mi355_am_set_input_exponents(self._h, x.ctypes.data_as(C.POINTER(C.c_int32)), x.shape[0]))
+
+    def calibrate(self, feats):
+        """f16x3 / f16: set every operand's exponent from CMVN'd features [T][feat_dim] (pk_mi355_am_calibrate)."""
+        feats = _f32(feats)
+        m = _as_matrix(feats)
+        _check(lib().pk_mi355_am_calibrate(self._h, C.byref(m)))
+        return self
+
     def propagate(self, x):
         """Nnet::Propagate (nnet.cc:149-163): x [T][in_dim] -> [T][out_dim]."""
         x = _f32(x)
@@ -516,6 +542,10 @@ class BatchScorer:
 
     def synchronize(self):
         _check(lib().pk_mi355_batch_synchronize(self._h))
+
+    def calibrate(self):
+        """f16x3 / f16: calibrate the model's operand exponents on the utterances currently set."""
+        _check(lib().pk_mi355_batch_calibrate(self._h))
 
     def num_utts(self):
         return lib().pk_mi355_batch_num_utts(self._h)

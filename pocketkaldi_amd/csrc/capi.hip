@@ -5,6 +5,7 @@
 #include <ctype.h>
 #include <dlfcn.h>
 #include <math.h>
+#include <cmath>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -181,6 +182,12 @@ struct pk_mi355_am {
   float *d_blob = nullptr;
   size_t blob_floats = 0;
   size_t logprior_off = 0;
+  // f16x3 / f16: the operand exponents, int32 words INSIDE the blob (so the one broadcast carries them):
+  // [w_exp of linear layer 0 .. n-1 | x_exp of the operand of linear layer 0 .. n-1 | 0].  The kernels read the
+  // device words; h_exps mirrors them on the host (refreshed from the device after a broadcast).
+  size_t exp_off = 0;
+  std::vector<int32_t> h_exps;
+  bool exps_stale = false;
   double flops_per_frame = 0;
   // The reference's pk_decodable_init / AcousticModel::Compute allocate per call and are re-entrant
   // for a shared model (nnet.cc:149-163 is const); here the single-utterance entry points share
@@ -205,6 +212,10 @@ struct ExecBufs {
   // plain input rows [rows_cap][2 Kpad0]; `a` holds the fp32 logits, `b` softmax probabilities
   _Float16 *h[2] = {nullptr, nullptr};
   _Float16 *xin = nullptr;
+  // f16x3 / f16: range words of the operand of every linear layer ([num linear][kRangeSlots], gemm_f16.hip:
+  // PublishRange) and their page-locked host mirror, read after the call (EvalRange)
+  uint32_t *range = nullptr, *h_range = nullptr;
+  int range_words = 0;
 };
 
 int AllocExec(const pk_mi355_am *am, int64_t rows_cap, ExecBufs *e) {
@@ -218,6 +229,11 @@ int AllocExec(const pk_mi355_am *am, int64_t rows_cap, ExecBufs *e) {
     }
     HIP_TRY(hipMalloc(&e->xin, xin));
     HIP_TRY(hipMemset(e->xin, 0, xin));
+    e->range_words = (int)am->lin.size() * kRangeSlots;
+    HIP_TRY(hipMalloc(&e->range, sizeof(uint32_t) * e->range_words));
+    HIP_TRY(hipMemset(e->range, 0, sizeof(uint32_t) * e->range_words));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_range), sizeof(uint32_t) * e->range_words, hipHostMallocDefault));
+    memset(e->h_range, 0, sizeof(uint32_t) * e->range_words);
   }
   e->act_floats = (int64_t)am->max_dim_pad * rows_cap;
   e->in_floats = RoundUp(am->input_dim, kBK) * rows_cap;
@@ -236,6 +252,8 @@ void FreeExec(ExecBufs *e) {
   hipFree(e->in);
   for (int i = 0; i < 2; ++i) hipFree(e->h[i]);
   hipFree(e->xin);
+  hipFree(e->range);
+  if (e->h_range) hipHostFree(e->h_range);
   *e = ExecBufs();
 }
 
@@ -245,6 +263,55 @@ struct ExecResult {
   int64_t ld = 0;
   int dim = 0;
 };
+
+// ---- f16x3 / f16 operand exponents and range words
+inline const int32_t *ExpBase(const pk_mi355_am *am) { return reinterpret_cast<const int32_t *>(am->d_blob + am->exp_off); }
+inline const int32_t *ExpW(const pk_mi355_am *am, int l) { return ExpBase(am) + l; }
+inline const int32_t *ExpX(const pk_mi355_am *am, int l) { return ExpBase(am) + am->lin.size() + l; }
+inline const int32_t *ExpZero(const pk_mi355_am *am) { return ExpBase(am) + 2 * am->lin.size(); }
+inline uint32_t *RangeOf(const ExecBufs &e, int l) { return e.range ? e.range + (size_t)l * kRangeSlots : nullptr; }
+
+constexpr int kMaxXExp = 30;                     // |operand exponent| (|w_exp| <= 40: 2^(e_out - e_in - e_w) stays a normal float)
+constexpr float kRangeSaturated = 65504.0f;      // the split clamps here (gemm_f16.hip: Split)
+constexpr float kRangeTooSmall = 0.03125f;       // 2^-5: below this every lo half of the operand is an fp16 subnormal
+                                                 // (|lo| <= 2^-12 |x|), and the mode degrades towards plain fp16
+
+int BeginRange(const ExecBufs &e, hipStream_t s) {
+  if (e.range) HIP_TRY(hipMemsetAsync(e.range, 0, sizeof(uint32_t) * e.range_words, s));
+  return 0;
+}
+int CollectRange(const ExecBufs &e, hipStream_t s) {
+  if (e.range) HIP_TRY(hipMemcpyAsync(e.h_range, e.range, sizeof(uint32_t) * e.range_words, hipMemcpyDeviceToHost, s));
+  return 0;
+}
+// max |hi| of operand l over the call whose range words have been collected (and its stream synchronised)
+float RangeMax(const ExecBufs &e, int l) {
+  uint32_t m = 0;
+  for (int i = 0; i < kRangeSlots; ++i) m = std::max(m, e.h_range[(size_t)l * kRangeSlots + i]);
+  float f;
+  memcpy(&f, &m, sizeof(f));
+  return f;
+}
+// The loud part of the f16 modes' contract: an operand that hit the clamp, or one so small that its lo halves
+// carry nothing, fails the call instead of returning numbers outside the advertised accuracy.
+int EvalRange(const pk_mi355_am *am, const ExecBufs *const *bufs, int nbufs) {
+  const int nlin = (int)am->lin.size();
+  for (int l = 0; l < nlin; ++l) {
+    float m = 0.0f;
+    for (int i = 0; i < nbufs; ++i)
+      if (bufs[i]->h_range) m = std::max(m, RangeMax(*bufs[i], l));
+    const int xe = am->exps_stale ? 0 : am->h_exps[nlin + l];
+    const char *mode = am->precision == PK_MI355_PRECISION_F16 ? "f16" : "f16x3";
+    if (m >= kRangeSaturated)
+      return Fail(PK_MI355_E_RANGE, "%s range: the input of affine layer %d saturated (|x| * 2^%d reached 65504, the fp16 split "
+                  "clamps there): results withheld; lower the operand's exponent (pk_mi355_am_calibrate)", mode, l, xe);
+    if (m > 0.0f && m < kRangeTooSmall)
+      return Fail(PK_MI355_E_RANGE, "%s range: the input of affine layer %d is too small for the fp16 split (max |x| * 2^%d = %g "
+                  "< 2^-5: every low half is subnormal): results withheld; raise the operand's exponent "
+                  "(pk_mi355_am_calibrate)", mode, l, xe, (double)m);
+  }
+  return 0;
+}
 
 // Run the layer stack on `rows` frames (rows_pad = multiple of 128, <= rows_cap).
 // Input: either the spliced view of Yt (splice_dim > 0: q0 points at Yt + first
@@ -417,13 +484,17 @@ int RunLayersF16(const pk_mi355_am *am, const ExecBufs &e, const _Float16 *x, in
     g.tiles_m = rows_pad / kTileF16;
     g.tiles_n = D.Npad / kTileF16;
     g.terms = am->precision == PK_MI355_PRECISION_F16 ? 1 : 3;
+    g.e_w = ExpW(am, li);
+    g.e_in = ExpX(am, li);
+    g.e_out = (last || norm) ? ExpZero(am) : ExpX(am, li + 1);
+    g.range = (last || norm) ? nullptr : RangeOf(e, li + 1);
     {
       Scoped t(timer, PK_MI355_K_GEMM, stream);
       LaunchGemmF16(g, stream);
     }
     if (norm) {
       Scoped t(timer, PK_MI355_K_OTHER, stream);
-      LaunchNormalizeSplitF16(e.a, D.Npad, rows_pad, D.N, D.Npad, e.h[buf], 2 * D.Npad, stream);
+      LaunchNormalizeSplitF16(e.a, D.Npad, rows_pad, D.N, D.Npad, e.h[buf], 2 * D.Npad, ExpX(am, li + 1), RangeOf(e, li + 1), stream);
     }
     x = e.h[buf]; ldx = 2 * D.Npad;
     out_ld = D.Npad;
@@ -784,6 +855,10 @@ int pk_mi355_am_finalize(pk_mi355_am_t *am, const float *prior, int num_pdfs, in
   am->max_dim_pad = max_pad;
   am->logprior_off = off;
   off += RoundUp(dim, 4);
+  am->exp_off = off;
+  const int nlin = (int)am->lin.size();
+  am->h_exps.assign(2 * nlin + 1, 0);
+  if (f16) off += RoundUp(2 * nlin + 1, 4);
   am->blob_floats = off;
 
   // pack: W^T zero-padded to [Kpad][Npad] (nnet.cc:16-17 keeps the transpose),
@@ -795,11 +870,28 @@ int pk_mi355_am_finalize(pk_mi355_am_t *am, const float *prior, int num_pdfs, in
     const DevLinear &D = am->lin[li++];
     if (f16) {
       // W stays [out][in] (k contiguous), split into fp16 hi and lo = fp16(w - hi), the
-      // pairs interleaved in chunks of 8 k's (see gemm_f16.hip)
+      // pairs interleaved in chunks of 8 k's (see gemm_f16.hip).
+      // Range safety: the layer's weights are first multiplied by 2^w_exp -- exact in fp32 -- chosen so that
+      // max |W| lands in [2^13, 2^14): every weight within 2^-16 of the largest then has a NORMAL lo half
+      // (lo = fp16(w - hi) needs |w| >= 2^-3 for that), whatever the scale the model was trained at; the GEMM's
+      // epilogue multiplies by 2^-w_exp again.  Unscaled, He-normal weights of a K = 1024 layer (max ~0.2) already
+      // have subnormal lo halves, and at 2^-8 of that scale the mode is no better than plain fp16.
+      float wmax = 0.0f;
+      for (size_t i = 0; i < (size_t)D.N * D.K; ++i) {
+        if (!std::isfinite(L.W[i]))
+          return Fail(PK_MI355_E_INVALID, "affine layer %d holds a non-finite weight (f16x3 / f16 precision cannot carry it)", (int)li - 1);
+        wmax = std::max(wmax, fabsf(L.W[i]));
+      }
+      // PK_MI355_NO_PRESCALE=1: measurement switch only (what the prescale costs in clock: normal lo halves toggle
+      // more bits than subnormal ones, and this mode is power-limited) -- never set it in production
+      static const bool no_prescale = [] { const char *e = getenv("PK_MI355_NO_PRESCALE"); return e && atoi(e) != 0; }();
+      const int w_exp = (wmax > 0.0f && !no_prescale) ? std::min(40, std::max(-40, 13 - ilogbf(wmax))) : 0;
+      am->h_exps[li - 1] = w_exp;
+      const float w_scale = ldexpf(1.0f, w_exp);
       _Float16 *w2 = reinterpret_cast<_Float16 *>(blob.data() + D.wt_off);
       for (int o = 0; o < D.N; ++o)
         for (int k = 0; k < D.K; ++k) {
-          float v = L.W[(size_t)o * D.K + k];
+          float v = L.W[(size_t)o * D.K + k] * w_scale;
           v = std::min(std::max(v, -65504.0f), 65504.0f);
           const _Float16 hi = static_cast<_Float16>(v);
           _Float16 *dst = w2 + (size_t)o * 2 * D.Kpad + (k >> 3) * 16 + (k & 7);
@@ -815,6 +907,7 @@ int pk_mi355_am_finalize(pk_mi355_am_t *am, const float *prior, int num_pdfs, in
   }
   for (int i = 0; i < dim; ++i)
     blob[am->logprior_off + i] = prior ? logf(prior[i]) : 0.0f;
+  if (f16) memcpy(blob.data() + am->exp_off, am->h_exps.data(), sizeof(int32_t) * am->h_exps.size());
   HIP_TRY(hipMalloc(&am->d_blob, sizeof(float) * off));
   HIP_TRY(hipMemcpy(am->d_blob, blob.data(), sizeof(float) * off, hipMemcpyHostToDevice));
 
@@ -993,7 +1086,12 @@ int pk_mi355_am_transition_to_pdf(const pk_mi355_am_t *am, int trans_id) {
   if (am->tid2pdf.empty()) return trans_id;
   return am->tid2pdf[trans_id];
 }
-void *pk_mi355_am_blob_device_ptr(pk_mi355_am_t *am) { return am ? am->d_blob : nullptr; }
+void *pk_mi355_am_blob_device_ptr(pk_mi355_am_t *am) {
+  if (!am) return nullptr;
+  if (IsF16(am->precision)) am->exps_stale = true;   // the caller may write the blob (a broadcast through another
+                                                     // library): the host mirror of its exponent words is re-read on need
+  return am->d_blob;
+}
 size_t pk_mi355_am_blob_bytes(const pk_mi355_am_t *am) { return am ? am->blob_floats * sizeof(float) : 0; }
 double pk_mi355_am_flops_per_frame(const pk_mi355_am_t *am) { return am ? am->flops_per_frame : 0; }
 
@@ -1041,6 +1139,20 @@ int BindRccl() {
 }
 }  // namespace
 
+namespace {
+// host mirror of the exponent words <- device (after a broadcast, or a write through the blob's device pointer)
+int RefreshExps(pk_mi355_am *am) {
+  if (!IsF16(am->precision) || !am->d_blob) { am->exps_stale = false; return 0; }
+  HIP_TRY(hipMemcpy(am->h_exps.data(), am->d_blob + am->exp_off, sizeof(int32_t) * am->h_exps.size(), hipMemcpyDeviceToHost));
+  am->exps_stale = false;
+  return 0;
+}
+int UploadExps(pk_mi355_am *am) {
+  HIP_TRY(hipMemcpy(am->d_blob + am->exp_off, am->h_exps.data(), sizeof(int32_t) * am->h_exps.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+}  // namespace
+
 int pk_mi355_am_broadcast_from(pk_mi355_am_t *am, pk_mi355_am_t *src, void *rccl_comm, int root, void *stream) {
   if (!am || !am->finalized) return Fail(PK_MI355_E_STATE, "model not finalized");
   if (src && (!src->finalized || src->blob_floats != am->blob_floats || src->device != am->device))
@@ -1063,10 +1175,12 @@ int pk_mi355_am_broadcast_from(pk_mi355_am_t *am, pk_mi355_am_t *src, void *rccl
     if (own) hipStreamDestroy(own);
     return Fail(PK_MI355_E_DEVICE, "ncclBroadcast failed: %s", g_nccl_error_string ? g_nccl_error_string(nr) : "?");
   }
+  am->exps_stale = IsF16(am->precision);     // the blob's exponent words now are the root's
   if (own) {
     hipError_t e = hipStreamSynchronize(own);
     hipStreamDestroy(own);
     if (e != hipSuccess) return Fail(PK_MI355_E_DEVICE, "broadcast stream: %s", hipGetErrorString(e));
+    return RefreshExps(am);
   }
   return 0;
 }
@@ -1093,8 +1207,10 @@ int pk_mi355_nnet_propagate(pk_mi355_am_t *am, const pk_matrix_t *in, pk_matrix_
     ExecResult res;
     if (IsF16(am->precision)) {
       const int kp = (int)RoundUp(D, kBKF16);
-      LaunchSplitF16(w->d_feats + r0 * D, D, 1, rows, D, kp, w->exec.xin, 2 * kp, w->stream);
+      if ((rc = BeginRange(w->exec, w->stream))) return rc;
+      LaunchSplitF16(w->d_feats + r0 * D, D, 1, rows, D, kp, w->exec.xin, 2 * kp, ExpX(am, 0), RangeOf(w->exec, 0), w->stream);
       rc = RunLayersF16(am, w->exec, w->exec.xin, 2 * kp, rows, false, 1.0f, nullptr, 0, w->stream, nullptr, &res);
+      if (!rc) rc = CollectRange(w->exec, w->stream);
     } else {
       LaunchTransposeToCols(w->d_feats + r0 * D, D, rows, D, w->exec.in, w->exec.rows_cap, w->stream);
       rc = RunLayers(am, w->exec, nullptr, 0, 0, rows, false, 1.0f, nullptr, 0, w->stream, nullptr, &res);
@@ -1104,9 +1220,46 @@ int pk_mi355_nnet_propagate(pk_mi355_am_t *am, const pk_matrix_t *in, pk_matrix_
                              sizeof(float) * res.ld, sizeof(float) * am->output_dim, rows,
                              hipMemcpyDeviceToHost, w->stream));
     HIP_TRY(hipStreamSynchronize(w->stream));
+    if (IsF16(am->precision)) {
+      const ExecBufs *eb = &w->exec;
+      if ((rc = EvalRange(am, &eb, 1))) { ResizeHostMatrix(out, 0, 0); return rc; }
+    }
   }
   return 0;
 }
+
+}  // extern "C"
+
+namespace {
+// The device half of pk_decodable_init (decodable.cc:8-17 -> am.cc:90-115), queued on the model's
+// single-utterance stream (am->mu held, workspace sized): features up, edge-padded transpose (am.cc:73-75),
+// the layer stack chunk by chunk; with want_tail the log-likelihoods land in ws->d_out.  In the f16 modes the
+// range words of the call are zeroed first and collected into the page-locked mirror last.
+int ScoreSingleQueue(pk_mi355_am *am, const pk_matrix_t *feats, bool want_tail, float prob_scale) {
+  Workspace *w = am->ws;
+  const int T = feats->ncol, D = feats->nrow, N = am->num_pdfs;
+  const bool f16 = IsF16(am->precision);
+  int rc;
+  HIP_TRY(hipMemcpyAsync(w->d_feats, feats->data, sizeof(float) * (size_t)T * D, hipMemcpyHostToDevice, w->stream));
+  LaunchPadTranspose(w->d_feats, T, D, am->left, am->right, w->d_yt, w->yt_ld, 0, w->stream);
+  if (f16) {
+    if ((rc = BeginRange(w->exec, w->stream))) return rc;
+    LaunchSplitF16(w->d_yt, 1, w->yt_ld, (int)w->yt_ld, D, D, w->d_y2, 2 * D, ExpX(am, 0), RangeOf(w->exec, 0), w->stream);
+  }
+  for (int64_t r0 = 0; r0 < T; r0 += kSingleChunk) {
+    const int rows = (int)std::min<int64_t>(kSingleChunk, T - r0);
+    rc = f16 ? RunLayersF16(am, w->exec, w->d_y2 + r0 * 2 * D, 2 * D, rows, want_tail, prob_scale,
+                            w->d_out + r0 * N, N, w->stream, nullptr, nullptr)
+             : RunLayers(am, w->exec, w->d_yt + r0, w->yt_ld, D, rows, want_tail, prob_scale,
+                         w->d_out + r0 * N, N, w->stream, nullptr, nullptr);
+    if (rc) return rc;
+  }
+  if (f16 && (rc = CollectRange(w->exec, w->stream))) return rc;
+  return 0;
+}
+}  // namespace
+
+extern "C" {
 
 // ------------------------------------------------------------------ decodable
 
@@ -1135,23 +1288,16 @@ void pk_decodable_init(pk_decodable_t *self, pk_mi355_am_t *am, float prob_scale
   if (EnsureWorkspace(am, T, D)) return;
   Workspace *w = am->ws;
   auto dev_fail = [&](hipError_t e) { Fail(PK_MI355_E_DEVICE, "HIP failure in pk_decodable_init: %s", hipGetErrorString(e)); };
-  hipError_t e = hipMemcpyAsync(w->d_feats, feats->data, sizeof(float) * (size_t)T * D, hipMemcpyHostToDevice, w->stream);
-  if (e != hipSuccess) { dev_fail(e); return; }
-  LaunchPadTranspose(w->d_feats, T, D, am->left, am->right, w->d_yt, w->yt_ld, 0, w->stream);
-  if (f16) LaunchSplitF16(w->d_yt, 1, w->yt_ld, (int)w->yt_ld, D, D, w->d_y2, 2 * D, w->stream);
-  for (int64_t r0 = 0; r0 < T; r0 += kSingleChunk) {
-    const int rows = (int)std::min<int64_t>(kSingleChunk, T - r0);
-    const int rc = f16 ? RunLayersF16(am, w->exec, w->d_y2 + r0 * 2 * D, 2 * D, rows, true, prob_scale,
-                                      w->d_out + r0 * N, N, w->stream, nullptr, nullptr)
-                       : RunLayers(am, w->exec, w->d_yt + r0, w->yt_ld, D, rows, true, prob_scale,
-                                   w->d_out + r0 * N, N, w->stream, nullptr, nullptr);
-    if (rc) return;
-  }
+  if (ScoreSingleQueue(am, feats, true, prob_scale)) return;
   float *host = static_cast<float *>(malloc(sizeof(float) * (size_t)T * N));   // util.cc:58-68 pk_alloc
   if (!host) { Fail(PK_MI355_E_INVALID, "out of host memory"); return; }
-  e = hipMemcpyAsync(host, w->d_out, sizeof(float) * (size_t)T * N, hipMemcpyDeviceToHost, w->stream);
+  hipError_t e = hipMemcpyAsync(host, w->d_out, sizeof(float) * (size_t)T * N, hipMemcpyDeviceToHost, w->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
   if (e != hipSuccess) { free(host); dev_fail(e); return; }
+  if (f16) {                      // an operand left the fp16 split's range: fail loudly, deliver nothing
+    const ExecBufs *eb = &w->exec;
+    if (EvalRange(am, &eb, 1)) { free(host); return; }
+  }
   self->log_prob.ncol = T;
   self->log_prob.nrow = N;
   self->log_prob.data = host;
@@ -1175,6 +1321,85 @@ float pk_decodable_loglikelihood(pk_decodable_t *self, int frame, int trans_id) 
 
 bool pk_decodable_islastframe(pk_decodable_t *self, int frame) {
   return frame == self->log_prob.ncol - 1;
+}
+
+// ------------------------------------------------------------------ f16 modes: operand exponents
+
+int pk_mi355_am_get_exponents(pk_mi355_am_t *am, int32_t *w_exp, int32_t *x_exp, int capacity) {
+  if (!am || !am->finalized) return Fail(PK_MI355_E_STATE, "model not finalized");
+  const int nlin = (int)am->lin.size();
+  if (capacity < nlin) return Fail(PK_MI355_E_INVALID, "room for %d exponents, the model has %d affine layers", capacity, nlin);
+  int rc = UseDevice(am->device);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(am->mu);
+  if (am->exps_stale && (rc = RefreshExps(am))) return rc;
+  for (int l = 0; l < nlin; ++l) {
+    if (w_exp) w_exp[l] = am->h_exps[l];
+    if (x_exp) x_exp[l] = am->h_exps[nlin + l];
+  }
+  return nlin;
+}
+
+int pk_mi355_am_set_input_exponents(pk_mi355_am_t *am, const int32_t *x_exp, int count) {
+  if (!am || !am->finalized) return Fail(PK_MI355_E_STATE, "model not finalized");
+  if (!IsF16(am->precision)) return Fail(PK_MI355_E_STATE, "operand exponents exist in the f16x3 / f16 precisions only");
+  const int nlin = (int)am->lin.size();
+  if (!x_exp || count != nlin) return Fail(PK_MI355_E_INVALID, "%d exponents expected (one per affine layer)", nlin);
+  for (int l = 0; l < nlin; ++l)
+    if (x_exp[l] < -kMaxXExp || x_exp[l] > kMaxXExp) return Fail(PK_MI355_E_INVALID, "exponent %d out of [-%d, %d]", x_exp[l], kMaxXExp, kMaxXExp);
+  int rc = UseDevice(am->device);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(am->mu);
+  if (am->exps_stale && (rc = RefreshExps(am))) return rc;
+  for (int l = 0; l < nlin; ++l) am->h_exps[nlin + l] = x_exp[l];
+  return UploadExps(am);
+}
+
+}  // extern "C"
+
+namespace {
+// One calibration decision from the range words of one pass (h_range of `e`, stream synchronised): the first
+// operand whose scaled maximum lies outside [2^9, 2^12) gets a new exponent that puts it into [2^10, 2^11) --
+// 32 x headroom below the clamp, 2^15 above the subnormal-lo threshold; a saturated one (true maximum unknown)
+// comes down by 2^12.  Later operands were computed from it, so the caller reruns before looking further.
+// Returns 1 if an exponent changed, 0 if every operand is in band.
+int CalibrateStep(pk_mi355_am *am, const ExecBufs &e) {
+  const int nlin = (int)am->lin.size();
+  for (int l = 0; l < nlin; ++l) {
+    const float m = RangeMax(e, l);
+    int32_t &xe = am->h_exps[nlin + l];
+    int want = xe;
+    if (m >= kRangeSaturated) want = xe - 12;
+    else if (m > 0.0f && (m < 512.0f || m >= 4096.0f)) want = xe + 10 - ilogbf(m);
+    want = std::min(kMaxXExp, std::max(-kMaxXExp, want));
+    if (want != xe) { xe = want; return 1; }
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int pk_mi355_am_calibrate(pk_mi355_am_t *am, const pk_matrix_t *feats) {
+  if (!am || !am->finalized) return Fail(PK_MI355_E_STATE, "model not finalized");
+  if (!IsF16(am->precision)) return 0;                       // nothing to calibrate: F32 carries every finite value
+  if (!feats || feats->nrow != am->feat_dim || feats->ncol <= 0 || !feats->data)
+    return Fail(PK_MI355_E_INVALID, "calibration features have %d rows, the model expects %d", feats ? feats->nrow : -1, am->feat_dim);
+  if (feats->nrow % 8 != 0) return Fail(PK_MI355_E_INVALID, "f16x3 / f16 precision needs a feature dimension that is a multiple of 8 (got %d)", feats->nrow);
+  int rc = UseDevice(am->device);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(am->mu);
+  if ((rc = EnsureWorkspace(am, feats->ncol, feats->nrow))) return rc;
+  if (am->exps_stale && (rc = RefreshExps(am))) return rc;
+  Workspace *w = am->ws;
+  const int max_passes = 6 * (int)am->lin.size() + 8;
+  for (int pass = 0; pass < max_passes; ++pass) {
+    if ((rc = ScoreSingleQueue(am, feats, false, 1.0f))) return rc;
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    if (!CalibrateStep(am, w->exec)) return 0;
+    if ((rc = UploadExps(am))) return rc;
+  }
+  return Fail(PK_MI355_E_RANGE, "calibration did not settle in %d passes", max_passes);
 }
 
 }  // extern "C"
@@ -1227,6 +1452,11 @@ struct pk_mi355_batch {
   hipEvent_t ev_front = nullptr, ev_lane2 = nullptr;
   ExecBufs exec;
   bool scored = false;
+  // f16 modes: the range words of the last score call wait in the page-locked mirrors until the stream has
+  // been synchronised; the verdict is then sticky until the next score (every delivering call repeats it)
+  bool range_pending = false;
+  int range_status = 0;
+  char range_msg[512] = "";
 };
 
 namespace {
@@ -1259,6 +1489,18 @@ int SetLayout(pk_mi355_batch *b, const int *num_samples, int num_utts) {
   HIP_TRY(hipMemcpyAsync(b->d_pad_base, b->h_pad_base.data(), sizeof(int64_t) * num_utts, hipMemcpyHostToDevice, b->stream));
   HIP_TRY(hipMemcpyAsync(b->d_T, b->h_T.data(), sizeof(int32_t) * num_utts, hipMemcpyHostToDevice, b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream));   // the host vectors may be reused right away
+  return 0;
+}
+
+// After the batch's stream has been synchronised: evaluate (once) the range words of the last score call.
+int BatchRangeStatus(pk_mi355_batch *b) {
+  if (b->range_pending) {
+    const ExecBufs *eb[2] = {&b->exec, &b->exec2};
+    b->range_status = EvalRange(b->am, eb, b->lanes == 2 ? 2 : 1);
+    if (b->range_status) snprintf(b->range_msg, sizeof(b->range_msg), "%s", g_err);
+    b->range_pending = false;
+  }
+  if (b->range_status) return Fail(b->range_status, "%s", b->range_msg);
   return 0;
 }
 
@@ -1426,13 +1668,15 @@ int pk_mi355_batch_score(pk_mi355_batch_t *b, float prob_scale, int sync) {
   const int N = am->num_pdfs;
   const bool f16 = IsF16(am->precision);
   if (f16) {
+    if ((rc = BeginRange(b->exec, b->stream))) return rc;
     Scoped t(tm, PK_MI355_K_OTHER, b->stream);
-    LaunchSplitF16(b->d_yt, 1, b->ldy, (int)b->ldy, kNumBins, kNumBins, b->d_y2, 2 * kNumBins, b->stream);
+    LaunchSplitF16(b->d_yt, 1, b->ldy, (int)b->ldy, kNumBins, kNumBins, b->d_y2, 2 * kNumBins, ExpX(am, 0), RangeOf(b->exec, 0), b->stream);
   }
   const bool two = b->lanes == 2 && b->total_cols > b->chunk;
   if (two) {                                   // lane 2 starts when the features are ready
     HIP_TRY(hipEventRecord(b->ev_front, b->stream));
     HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_front, 0));
+    if (f16 && (rc = BeginRange(b->exec2, b->stream2))) return rc;
   }
   int lane = 0;
   for (int64_t c0 = 0; c0 < b->total_cols; c0 += b->chunk, lane ^= 1) {
@@ -1446,18 +1690,49 @@ int pk_mi355_batch_score(pk_mi355_batch_t *b, float prob_scale, int sync) {
     if (rc) return rc;
   }
   if (two) {                                   // everything is ordered on b->stream again
+    if (f16 && (rc = CollectRange(b->exec2, b->stream2))) return rc;
     HIP_TRY(hipEventRecord(b->ev_lane2, b->stream2));
     HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_lane2, 0));
   }
+  if (f16) {
+    if ((rc = CollectRange(b->exec, b->stream))) return rc;
+    b->range_pending = true;
+    b->range_status = 0;
+  }
   b->scored = true;
-  if (sync) HIP_TRY(hipStreamSynchronize(b->stream));
+  if (sync) return pk_mi355_batch_synchronize(b);
   return 0;
 }
 
 int pk_mi355_batch_synchronize(pk_mi355_batch_t *b) {
   if (!b) return Fail(PK_MI355_E_INVALID, "null batch");
   HIP_TRY(hipStreamSynchronize(b->stream));
-  return 0;
+  return BatchRangeStatus(b);
+}
+
+int pk_mi355_batch_calibrate(pk_mi355_batch_t *b) {
+  if (!b) return Fail(PK_MI355_E_INVALID, "null batch");
+  pk_mi355_am *am = b->am;
+  if (!IsF16(am->precision)) return 0;
+  if (!b->wave_f32 && !b->wave_i16) return Fail(PK_MI355_E_STATE, "no waves set");
+  if (b->total_frames == 0) return Fail(PK_MI355_E_INVALID, "calibration needs at least one frame");
+  int rc = UseDevice(b->device);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(am->mu);
+  if (am->exps_stale && (rc = RefreshExps(am))) return rc;
+  const int max_passes = 6 * (int)am->lin.size() + 8;
+  for (int pass = 0; pass < max_passes; ++pass) {
+    rc = pk_mi355_batch_score(b, 1.0f, 0);
+    b->scored = false;                           // calibration passes are not results
+    b->range_pending = false;
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (b->lanes == 2)
+      for (int i = 0; i < b->exec.range_words; ++i) b->exec.h_range[i] = std::max(b->exec.h_range[i], b->exec2.h_range[i]);
+    if (!CalibrateStep(am, b->exec)) return 0;
+    if ((rc = UploadExps(am))) return rc;
+  }
+  return Fail(PK_MI355_E_RANGE, "calibration did not settle in %d passes", max_passes);
 }
 
 int pk_mi355_batch_num_utts(const pk_mi355_batch_t *b) { return b ? b->num_utts : 0; }
@@ -1486,6 +1761,7 @@ int pk_mi355_batch_fetch(pk_mi355_batch_t *b, int utt, pk_decodable_t *out) {
                                 hipMemcpyDeviceToHost, b->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
   if (e != hipSuccess) { free(host); return Fail(PK_MI355_E_DEVICE, "fetch: %s", hipGetErrorString(e)); }
+  if ((rc = BatchRangeStatus(b))) { free(host); return rc; }      // f16 modes: out-of-range results are withheld
   out->log_prob.ncol = T; out->log_prob.nrow = N; out->log_prob.data = host;
   return 0;
 }
@@ -1529,7 +1805,14 @@ int pk_mi355_batch_fetch_all(pk_mi355_batch_t *b, pk_decodable_t *out, int num_o
     out[u].log_prob.nrow = T > 0 ? N : 0;
     out[u].log_prob.data = T > 0 ? b->h_ll + (size_t)b->h_pad_base[u] * N : nullptr;
   }
-  if (sync) HIP_TRY(hipStreamSynchronize(b->stream));
+  if (sync && (rc = pk_mi355_batch_synchronize(b))) {   // f16 modes: the range verdict of the score call comes with it
+    for (int u = 0; u < num_out; ++u) {                 // nothing is delivered: hand back empty decodables, drop the views
+      ReleaseArenaView(gen);
+      out[u].am = b->am;
+      out[u].log_prob.ncol = 0; out[u].log_prob.nrow = 0; out[u].log_prob.data = nullptr;
+    }
+    return rc;
+  }
   return 0;
 }
 

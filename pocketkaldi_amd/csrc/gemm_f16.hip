@@ -52,6 +52,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 typedef const __attribute__((address_space(1))) void *GlobalPtr;
 typedef __attribute__((address_space(3))) void *LdsPtr;
@@ -85,6 +88,54 @@ __device__ __forceinline__ SplitOut Split(float v) {
   s.hi = static_cast<_Float16>(v);
   s.lo = static_cast<_Float16>(v - static_cast<float>(s.hi));
   return s;
+}
+
+// 2^e as a float (|e| <= 126: the host clamps the exponents it stores)
+__device__ __forceinline__ float Pow2(int e) { return __int_as_float((127 + e) << 23); }
+
+// Range word of an operand: the largest |hi| some wave wrote, kept as the bit pattern of a non-negative float
+// (unsigned order = float order).  One relaxed read + at most one fire-and-forget atomic per wave; the words of
+// an operand are spread over kRangeSlots addresses so the atomics of a launch do not queue on one L2 line.
+// The host reads them after the call: >= 65504 means the split clamped (saturation), a positive value below
+// 2^-5 means every lo half of the operand was subnormal (capi.hip: EvalRange).
+__device__ __forceinline__ void PublishRange(uint32_t *range, int slot, float wave_max) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) wave_max = fmaxf(wave_max, __shfl_xor(wave_max, m));
+  if ((threadIdx.x & 63) == 0) {
+    const uint32_t bits = __float_as_uint(wave_max);
+    uint32_t *w = range + (slot & (kRangeSlots - 1));
+    if (bits > __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(w, bits);
+  }
+}
+
+// Running maximum of |hi| over packed halves, taken on the BIT PATTERNS as signed 16-bit integers (v_pk_max_i16:
+// half an instruction per value, no NaN canonicalisation, no dependent fp latency): for non-negative halves the
+// integer order is the float order, and -0.0 (0x8000) sorts below everything.  NONNEG: the values went through
+// a ReLU; otherwise the sign bits are cleared first.
+template <bool NONNEG>
+__device__ __forceinline__ s16x4 RangeAcc(s16x4 m, f16x4 hi) {
+  s16x4 b = __builtin_bit_cast(s16x4, hi);
+  if (!NONNEG) b &= (short)0x7fff;
+  return __builtin_elementwise_max(m, b);
+}
+template <bool NONNEG>
+__device__ __forceinline__ s16x2 RangeAcc(s16x2 m, f16x2 hi) {
+  s16x2 b = __builtin_bit_cast(s16x2, hi);
+  if (!NONNEG) b &= (short)0x7fff;
+  return __builtin_elementwise_max(m, b);
+}
+__device__ __forceinline__ float RangeValue(short bits) {      // the fp16 whose (non-negative) pattern won
+  return static_cast<float>(__builtin_bit_cast(_Float16, bits));
+}
+
+// The three exponent words of a launch (wave-uniform, fetched before the first DMA is issued: left to the
+// compiler they became vector loads at the top of the epilogue, a full memory round trip with the matrix pipes idle).
+struct Exps { int e_in_w, e_out; };
+__device__ __forceinline__ Exps LoadExps(const GemmF16Args &a, bool last) {
+  Exps e;
+  e.e_in_w = __builtin_amdgcn_readfirstlane(*a.e_in + *a.e_w);
+  e.e_out = last ? 0 : __builtin_amdgcn_readfirstlane(*a.e_out);
+  return e;
 }
 
 // Diagnostic build only (tools/ubench/f16_gemm_probe.hip defines PK_F16_STAMPS): s_memtime stamps
@@ -121,6 +172,7 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;          // 2 x 4 waves
   const int l31 = lane & 31, kg = lane >> 5;
+  const Exps ex = LoadExps(a, LAST);
 
   // ---- DMA role of this lane: pieces 2 wave, 2 wave + 1 of X and of W; a piece is 16
   // LDS rows, lane -> row (lane >> 2), stored position (lane & 3)
@@ -299,7 +351,10 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
   // per lane: one store instruction = four whole 256-byte row pieces.  No barrier: a wave reads
   // back only what it wrote itself.
   const int M0 = m0 + wm * 128, N0 = n0 + wn * 64 + 2 * l31;
-  const f32x2 bias = *reinterpret_cast<const f32x2 *>(a.bias + N0);
+  // operand exponents (gemm_f16.hip header of GemmF16K32Kernel's epilogue): v = acc * 2^(e_out - e_in - e_w) + bias * 2^e_out
+  const float acc_scale = Pow2(ex.e_out - ex.e_in_w);
+  const f32x2 bias = *reinterpret_cast<const f32x2 *>(a.bias + N0) * Pow2(ex.e_out);
+  s16x2 hmax = s16x2{0, 0};
   unsigned char *stage = smem + wave * (2 * 8192);
   // byte offset of this lane's pair in a staged row: fp32 pair, or the (hi, lo) halves of chunk l31 / 4
   const int pair_byte = LAST ? l31 * 8 : (l31 >> 2) * 32 + (l31 & 3) * 4;
@@ -313,7 +368,7 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
-      float v0 = acc[x][0][r] + bias[0], v1 = acc[x][1][r] + bias[1];
+      float v0 = __builtin_fmaf(acc[x][0][r], acc_scale, bias[0]), v1 = __builtin_fmaf(acc[x][1][r], acc_scale, bias[1]);
       if (RELU) {               // one v_max_f32 (folds into the split's clamp); NaN / -0.0 are not carried by this mode
         v0 = fmaxf(v0, 0.0f);
         v1 = fmaxf(v1, 0.0f);
@@ -322,7 +377,9 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
         *reinterpret_cast<f32x2 *>(buf + row * 256 + pair_byte) = f32x2{v0, v1};
       } else {
         const SplitOut s0 = Split(v0), s1 = Split(v1);
-        *reinterpret_cast<f16x2 *>(buf + row * 256 + pair_byte) = f16x2{s0.hi, s1.hi};
+        const f16x2 hi = f16x2{s0.hi, s1.hi};
+        hmax = RangeAcc<RELU>(hmax, hi);
+        *reinterpret_cast<f16x2 *>(buf + row * 256 + pair_byte) = hi;
         *reinterpret_cast<f16x2 *>(buf + row * 256 + pair_byte + 16) = f16x2{s0.lo, s1.lo};
       }
     }
@@ -335,6 +392,8 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
       *reinterpret_cast<f32x4v *>(out_rows + (int64_t)(32 * x + row) * row_bytes + (lane & 15) * 16) = v;
     }
   }
+  if (!LAST && a.range)
+    PublishRange(a.range, blockIdx.x * 8 + wave, RangeValue(hmax[0] > hmax[1] ? hmax[0] : hmax[1]));
 #ifdef PK_F16_STAMPS
   if (lane == 0 && blockIdx.x < 256) {
     long long *o = pk_f16_stamps + (blockIdx.x * 8 + wave) * 8;
@@ -398,6 +457,7 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;          // 2 x 4 waves
   const int l15 = lane & 15, g = lane >> 4;
+  const Exps ex = LoadExps(a, LAST);
 
   // ---- DMA role of this lane: as in the 32 x 32 form (pieces 2 wave, 2 wave + 1 of X and of W of
   // every half-slab; a piece is 16 LDS rows, lane -> row lane >> 2, stored position lane & 3); the W rows
@@ -558,14 +618,20 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a
   // halves in chunks of 8 -- and written out 16 bytes per lane: one store instruction = four whole
   // 256-byte row pieces.  No barrier: a wave reads back only what it wrote itself.
   const int M0 = m0 + wm * 128, N0 = n0 + wn * 64 + 4 * l15;
-  const f32x4v bias = *reinterpret_cast<const f32x4v *>(a.bias + N0);
+  // Operand exponents: the accumulators hold sum (X 2^e_in)(W 2^e_w); what is written is
+  //   v 2^e_out,  v = acc 2^-(e_in + e_w) + bias        (nnet.cc:32-35)
+  // as ONE fma per value, acc * 2^(e_out - e_in - e_w) + bias * 2^e_out: every factor is a power of two, so this is
+  // the rounding of v itself, scaled exactly (ReLU commutes with a positive factor).  Costs what the plain bias
+  // add cost (v_pk_fma_f32 for v_pk_add_f32).  e_out is 0 for fp32 output.
+  const float acc_scale = Pow2(ex.e_out - ex.e_in_w);
+  const f32x4v bias = *reinterpret_cast<const f32x4v *>(a.bias + N0) * Pow2(ex.e_out);
+  const f32x4v acc_scale4 = f32x4v{acc_scale, acc_scale, acc_scale, acc_scale};
   unsigned char *stage = smem + wave * (2 * 8192);
   // byte offset of this lane's four columns in a staged row: fp32 quad, or the hi halves of chunk l15 / 2
   const int quad_byte = LAST ? l15 * 16 : (l15 >> 1) * 32 + (l15 & 1) * 8;
   unsigned char *out_rows = LAST ? reinterpret_cast<unsigned char *>(a.out_f32 + (int64_t)M0 * a.ldo + n0 + wn * 64)
                                  : reinterpret_cast<unsigned char *>(a.out + (int64_t)M0 * a.ldo + 2 * (n0 + wn * 64));
   const int64_t row_bytes = a.ldo * (LAST ? (int64_t)sizeof(float) : (int64_t)sizeof(_Float16));
-  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   // bias and ReLU on whole accumulator vectors: the add pairs up (v_pk_add_f32), the ReLU is one v_max_f32.  (max
   // instead of the reference's x < 0 ? 0 : x differs for NaN and -0.0 only, which this mode's saturating split
   // does not carry anyway.)
@@ -573,12 +639,13 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a
   for (int x = 0; x < 8; ++x)
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
-      acc[x][y] += f32x4v{bias[y], bias[y], bias[y], bias[y]};
+      acc[x][y] = __builtin_elementwise_fma(acc[x][y], acc_scale4, f32x4v{bias[y], bias[y], bias[y], bias[y]});
       if (RELU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[x][y][r] = fmaxf(acc[x][y][r], 0.0f);
       }
     }
+  s16x4 hmax[2] = {s16x4{0, 0, 0, 0}, s16x4{0, 0, 0, 0}};   // range word of the operand written here: max |hi| (RangeAcc), two chains
 #pragma unroll
   for (int xp = 0; xp < 4; ++xp) {
     unsigned char *buf = stage + (xp & 1) * 8192;
@@ -595,7 +662,9 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a
           *reinterpret_cast<f32x4v *>(buf + row * 256 + quad_byte) = f32x4v{v[0], v[1], v[2], v[3]};
         } else {
           const SplitOut s0 = Split(v[0]), s1 = Split(v[1]), s2 = Split(v[2]), s3 = Split(v[3]);
-          *reinterpret_cast<f16x4 *>(buf + row * 256 + quad_byte) = f16x4{s0.hi, s1.hi, s2.hi, s3.hi};
+          const f16x4 hi = f16x4{s0.hi, s1.hi, s2.hi, s3.hi};
+          hmax[r & 1] = RangeAcc<RELU>(hmax[r & 1], hi);
+          *reinterpret_cast<f16x4 *>(buf + row * 256 + quad_byte) = hi;
           *reinterpret_cast<f16x4 *>(buf + row * 256 + quad_byte + 16) = f16x4{s0.lo, s1.lo, s2.lo, s3.lo};
         }
       }
@@ -608,6 +677,11 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a
       const f32x4v v = *reinterpret_cast<const f32x4v *>(buf + row * 256 + (lane & 15) * 16);
       *reinterpret_cast<f32x4v *>(out_rows + (int64_t)(32 * xp + row) * row_bytes + (lane & 15) * 16) = v;
     }
+  }
+  if (!LAST && a.range) {
+    const s16x4 h4 = __builtin_elementwise_max(hmax[0], hmax[1]);
+    const s16x2 h2 = __builtin_elementwise_max(s16x2{h4[0], h4[1]}, s16x2{h4[2], h4[3]});
+    PublishRange(a.range, blockIdx.x * 8 + wave, RangeValue(h2[0] > h2[1] ? h2[0] : h2[1]));
   }
 #ifdef PK_F16_STAMPS
   if (lane == 0 && blockIdx.x < 256) {
@@ -628,22 +702,44 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a
 // (c / 8) * 16 + c % 8 (hi) and 8 halves further (lo); columns cols..cols_pad-1 are zero.
 __global__ void SplitKernel(const float *__restrict__ in, int64_t stride_r, int64_t stride_c,
                             int rows, int cols, int cols_pad, _Float16 *__restrict__ out,
-                            int64_t ld_out) {
+                            int64_t ld_out, const int32_t *__restrict__ e_x, uint32_t *range) {
   const int64_t total = (int64_t)rows * cols_pad;
+  const float sc = e_x ? Pow2(*e_x) : 1.0f;
+  float hmax = 0.0f;
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int r = idx / cols_pad, c = idx % cols_pad;
-    const float v = c < cols ? in[(int64_t)r * stride_r + (int64_t)c * stride_c] : 0.0f;
+    const float v = c < cols ? in[(int64_t)r * stride_r + (int64_t)c * stride_c] * sc : 0.0f;
     const SplitOut s = Split(v);
+    hmax = fmaxf(hmax, fabsf(static_cast<float>(s.hi)));
     _Float16 *o = out + (int64_t)r * ld_out + (c >> 3) * 16 + (c & 7);
     o[0] = s.hi;
     o[8] = s.lo;
   }
+  if (range) PublishRange(range, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), hmax);
 }
 
 }  // namespace
 
-void LaunchGemmF16(const GemmF16Args &a, hipStream_t stream) {
+namespace {
+// a zero exponent word for callers that scale nothing (probes, tests): one per device, made on first use
+const int32_t *ZeroWord() {
+  static std::mutex mu;
+  static int32_t *word[64] = {};
+  int dev = 0;
+  hipGetDevice(&dev);
+  std::lock_guard<std::mutex> g(mu);
+  if (dev < 0 || dev >= 64) return nullptr;
+  if (!word[dev] && hipMalloc(&word[dev], sizeof(int32_t)) == hipSuccess) hipMemset(word[dev], 0, sizeof(int32_t));
+  return word[dev];
+}
+}  // namespace
+
+void LaunchGemmF16(const GemmF16Args &a_in, hipStream_t stream) {
+  GemmF16Args a = a_in;
+  if (!a.e_w) a.e_w = ZeroWord();
+  if (!a.e_in) a.e_in = ZeroWord();
+  if (!a.e_out) a.e_out = ZeroWord();
   const int super_m = (a.tiles_m + 3) / 4, super_n = (a.tiles_n + 3) / 4;
   const int nblk = super_m * super_n * 16;
   dim3 grid(nblk), block(kThreadsF16);
@@ -693,10 +789,11 @@ void LaunchGemmF16(const GemmF16Args &a, hipStream_t stream) {
 // float sum: this mode is not bit-exact anyway (1e-4 contract).  Columns n .. npad - 1 are written as zeros.
 namespace {
 __global__ __launch_bounds__(256) void NormalizeSplitKernel(const float *__restrict__ in, int64_t ld_in, int rows, int n,
-                                                            int npad, _Float16 *__restrict__ out, int64_t ld_out) {
+                                                            int npad, _Float16 *__restrict__ out, int64_t ld_out,
+                                                            const int32_t *__restrict__ e_x, uint32_t *range) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  if (row >= rows) return;                      // wave-uniform
   const float *x = in + (int64_t)row * ld_in;
   float ssq = 0.0f;
   for (int c = lane * 8; c < npad; c += 64 * 8) {
@@ -711,7 +808,10 @@ __global__ __launch_bounds__(256) void NormalizeSplitKernel(const float *__restr
   for (int m = 32; m >= 1; m >>= 1) ssq += __shfl_xor(ssq, m);
   // nnet.cc:70-72.  An all-zero row makes the reference produce NaN (0 * inf, no epsilon: SURVEY a17); this mode's
   // operands cannot carry NaN (the split saturates, include/pk_mi355.h), so such a row stays all-zero here
-  const float scale = ssq > 0.0f ? static_cast<float>(sqrt(static_cast<double>(n) / static_cast<double>(ssq))) : 0.0f;
+  // the operand's exponent rides on the row's scale: (x * scale) * 2^e == x * (scale * 2^e) exactly
+  const float scale = (ssq > 0.0f ? static_cast<float>(sqrt(static_cast<double>(n) / static_cast<double>(ssq))) : 0.0f) *
+                      (e_x ? Pow2(*e_x) : 1.0f);
+  float hmax = 0.0f;
   _Float16 *o = out + (int64_t)row * ld_out;
   for (int c = lane * 8; c < npad; c += 64 * 8) {
     const f32x4v a = *reinterpret_cast<const f32x4v *>(x + c), b = *reinterpret_cast<const f32x4v *>(x + c + 4);
@@ -722,27 +822,31 @@ __global__ __launch_bounds__(256) void NormalizeSplitKernel(const float *__restr
       const SplitOut sp = Split(c + e < n ? v * scale : 0.0f);
       hi[e] = sp.hi;
       lo[e] = sp.lo;
+      hmax = fmaxf(hmax, fabsf(static_cast<float>(sp.hi)));
     }
     *reinterpret_cast<f16x8 *>(o + 2 * c) = hi;
     *reinterpret_cast<f16x8 *>(o + 2 * c + 8) = lo;
   }
+  if (range) PublishRange(range, row, hmax);
 }
 }  // namespace
 
 void LaunchNormalizeSplitF16(const float *in, int64_t ld_in, int rows, int n, int npad, _Float16 *out, int64_t ld_out,
-                             hipStream_t stream) {
+                             const int32_t *e_x, uint32_t *range, hipStream_t stream) {
   if (rows <= 0 || n <= 0) return;
-  hipLaunchKernelGGL(NormalizeSplitKernel, dim3((rows + 3) / 4), dim3(256), 0, stream, in, ld_in, rows, n, npad, out, ld_out);
+  hipLaunchKernelGGL(NormalizeSplitKernel, dim3((rows + 3) / 4), dim3(256), 0, stream, in, ld_in, rows, n, npad, out, ld_out,
+                     e_x, range);
 }
 
 void LaunchSplitF16(const float *in, int64_t stride_r, int64_t stride_c, int rows, int cols,
-                    int cols_pad, _Float16 *out, int64_t ld_out, hipStream_t stream) {
+                    int cols_pad, _Float16 *out, int64_t ld_out, const int32_t *e_x, uint32_t *range,
+                    hipStream_t stream) {
   if (rows <= 0 || cols_pad <= 0) return;
   int64_t n = (int64_t)rows * cols_pad;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(SplitKernel, dim3(blocks), dim3(256), 0, stream, in, stride_r, stride_c, rows,
-                     cols, cols_pad, out, ld_out);
+                     cols, cols_pad, out, ld_out, e_x, range);
 }
 
 }  // namespace pkmi

@@ -101,7 +101,16 @@ struct GemmF16Args {
   int64_t ldo;           // floats (out_f32) or halves (out)
   int tiles_m, tiles_n;  // 256 x 256 tiles
   int terms = 3;         // 3: hi hi + hi lo + lo hi (f16x3); 1: hi hi only (plain fp16 operands)
+  // Power-of-two operand scaling (device words, part of the model blob so that the one broadcast carries
+  // them): the operands hold X * 2^e_in and W * 2^e_w; the epilogue undoes both and applies the exponent of
+  // the NEXT layer's operand, 2^e_out, to what it writes as (hi, lo) halves (e_out points at a zero word for
+  // fp32 output).  All three exact in fp32.
+  const int32_t *e_w = nullptr, *e_in = nullptr, *e_out = nullptr;
+  // Range words of the operand this launch writes (kRangeSlots uint32, or nullptr for fp32 output):
+  // slot s receives max |hi| of the halves some wave wrote, as the bit pattern of a non-negative float.
+  uint32_t *range = nullptr;
 };
+constexpr int kRangeSlots = 256;
 void LaunchGemmF16(const GemmF16Args &a, hipStream_t stream);
 
 // fp32 -> interleaved (hi, lo) fp16 rows: element (r, c) read at in[r * stride_r + c *
@@ -109,10 +118,13 @@ void LaunchGemmF16(const GemmF16Args &a, hipStream_t stream);
 // cols..cols_pad-1 are zero-filled (cols_pad multiple of 8).
 // NormalizeLayer (nnet.cc:62-75) between two f16x3 layers: fp32 rows [rows][ld_in] -> normalized interleaved
 // (hi, lo) rows [rows][ld_out halves]; columns n..npad-1 zero (npad a multiple of 8, <= ld_in).
+// e_x: device word, the operand's exponent (values are split as x * 2^e_x); range: its kRangeSlots range words
+// (either may be nullptr: exponent 0 / no range tracking).
 void LaunchNormalizeSplitF16(const float *in, int64_t ld_in, int rows, int n, int npad, _Float16 *out, int64_t ld_out,
-                             hipStream_t stream);
+                             const int32_t *e_x, uint32_t *range, hipStream_t stream);
 void LaunchSplitF16(const float *in, int64_t stride_r, int64_t stride_c, int rows, int cols,
-                    int cols_pad, _Float16 *out, int64_t ld_out, hipStream_t stream);
+                    int cols_pad, _Float16 *out, int64_t ld_out, const int32_t *e_x, uint32_t *range,
+                    hipStream_t stream);
 
 // ---------------------------------------------------------------- row-wise / elementwise
 
