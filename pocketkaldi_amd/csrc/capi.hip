@@ -609,7 +609,12 @@ int ResizeHostMatrix(pk_matrix_t *m, int nrow, int ncol) {
 // keeps the arena until the process ends.)
 //
 // Every fetch_all makes one ViewGen -- the generation its views belong to -- and a view's `am` field
-// points at it (tagged, bit 0; opaque to every caller, the four pk_decodable_* functions resolve it).
+// points at it (tagged, bit 0; opaque to every caller; pk_decodable_destroy and pk_decodable_loglikelihood resolve it).
+// ViewGen records are 64-byte aligned and RECYCLED, never returned to the heap: bits 1-5 of a handle carry the
+// record's serial, which moves on every time the record is retired, and retired records are reused oldest first --
+// a bitwise copy of a view that has already been destroyed therefore names a (record, serial) pair that is not
+// alive and is ignored, also after the record has been given to a later fetch_all (the guard used
+// to key on the record's address alone).
 // A view therefore always decrements the count of ITS OWN generation: a stale view of an earlier
 // fetch_all, or of another batch whose arena once occupied the same addresses, can never drive the
 // current generation's count to zero under views that are still outstanding (the
@@ -618,11 +623,12 @@ int ResizeHostMatrix(pk_matrix_t *m, int nrow, int ncol) {
 namespace {
 std::mutex g_arena_mu;
 struct ArenaRec;
-struct ViewGen {
+struct alignas(64) ViewGen {
   pk_mi355_am_t *am;     // what Untag() resolves a view's handle to
   ArenaRec *arena;       // valid while `current`
   int live;              // views of this generation not yet destroyed
   bool current;          // the batch's latest fetch_all
+  unsigned serial;       // 0..31, part of the handle
 };
 struct ArenaRec {
   void *mem;
@@ -632,10 +638,32 @@ struct ArenaRec {
 // live generations: a handle that is not in here (a view destroyed twice through a bitwise copy)
 // is ignored instead of dereferenced
 std::unordered_set<const ViewGen *> g_gens;
+std::vector<ViewGen *> g_retired;     // FIFO of records waiting for reuse (head index below)
+size_t g_retired_head = 0;
 
 inline bool IsView(const pk_mi355_am_t *am) { return (reinterpret_cast<uintptr_t>(am) & 1u) != 0; }
-inline ViewGen *GenOf(const pk_mi355_am_t *am) { return reinterpret_cast<ViewGen *>(reinterpret_cast<uintptr_t>(am) & ~uintptr_t(1)); }
-inline pk_mi355_am_t *TagView(ViewGen *g) { return reinterpret_cast<pk_mi355_am_t *>(reinterpret_cast<uintptr_t>(g) | 1u); }
+inline ViewGen *GenOf(const pk_mi355_am_t *am) { return reinterpret_cast<ViewGen *>(reinterpret_cast<uintptr_t>(am) & ~uintptr_t(63)); }
+inline unsigned SerialOf(const pk_mi355_am_t *am) { return (unsigned)((reinterpret_cast<uintptr_t>(am) >> 1) & 31u); }
+inline pk_mi355_am_t *TagView(ViewGen *g) { return reinterpret_cast<pk_mi355_am_t *>(reinterpret_cast<uintptr_t>(g) | (uintptr_t(g->serial) << 1) | 1u); }
+// under g_arena_mu
+ViewGen *NewGenRecord(pk_mi355_am_t *am, ArenaRec *a, int views) {
+  ViewGen *v;
+  if (g_retired.size() - g_retired_head >= 64) {       // reuse only once 64 later records have been retired after it
+    v = g_retired[g_retired_head++];
+    if (g_retired_head > 4096) { g_retired.erase(g_retired.begin(), g_retired.begin() + g_retired_head); g_retired_head = 0; }
+  } else {
+    v = new ViewGen();
+    v->serial = 0;
+  }
+  v->am = am; v->arena = a; v->live = views; v->current = true;
+  g_gens.insert(v);
+  return v;
+}
+void RetireGenRecord(ViewGen *v) {
+  g_gens.erase(v);
+  v->serial = (v->serial + 1) & 31u;
+  g_retired.push_back(v);
+}
 // the model behind a decodable's handle (lock-free: a live view keeps its generation alive)
 inline pk_mi355_am_t *Untag(pk_mi355_am_t *am) { return IsView(am) ? GenOf(am)->am : am; }
 
@@ -646,10 +674,9 @@ pk_mi355_am_t *NewViewGen(ArenaRec *a, pk_mi355_am_t *am, int views) {
   std::lock_guard<std::mutex> g(g_arena_mu);
   if (a->cur) {
     a->cur->current = false;
-    if (a->cur->live <= 0) { g_gens.erase(a->cur); delete a->cur; }
+    if (a->cur->live <= 0) RetireGenRecord(a->cur);
   }
-  a->cur = new ViewGen{am, a, views, true};
-  g_gens.insert(a->cur);
+  a->cur = NewGenRecord(am, a, views);
   return TagView(a->cur);
 }
 // The batch is going away: release the arena now, or leave that to the last view of its last fetch_all.
@@ -659,7 +686,7 @@ void RetireArena(ArenaRec *a) {
     std::lock_guard<std::mutex> g(g_arena_mu);
     a->batch_alive = false;
     if (!a->cur || a->cur->live <= 0) {
-      if (a->cur) { g_gens.erase(a->cur); delete a->cur; }
+      if (a->cur) RetireGenRecord(a->cur);
       release = a->mem;
       delete a;
     }
@@ -673,7 +700,7 @@ void ReleaseArenaView(pk_mi355_am_t *handle) {
   {
     std::lock_guard<std::mutex> g(g_arena_mu);
     ViewGen *v = GenOf(handle);
-    if (!g_gens.count(v)) return;                 // generation already gone: a copy destroyed twice
+    if (!g_gens.count(v) || v->serial != SerialOf(handle)) return;   // generation already gone: a copy destroyed twice
     if (--v->live > 0) return;
     if (v->current) {
       ArenaRec *a = v->arena;
@@ -681,8 +708,7 @@ void ReleaseArenaView(pk_mi355_am_t *handle) {
       release = a->mem;
       delete a;
     }
-    g_gens.erase(v);
-    delete v;
+    RetireGenRecord(v);
   }
   if (release) hipHostFree(release);
 }
@@ -1257,6 +1283,7 @@ int ScoreSingleQueue(pk_mi355_am *am, const pk_matrix_t *feats, bool want_tail, 
   if (f16 && (rc = CollectRange(w->exec, w->stream))) return rc;
   return 0;
 }
+
 }  // namespace
 
 extern "C" {
@@ -1288,16 +1315,24 @@ void pk_decodable_init(pk_decodable_t *self, pk_mi355_am_t *am, float prob_scale
   if (EnsureWorkspace(am, T, D)) return;
   Workspace *w = am->ws;
   auto dev_fail = [&](hipError_t e) { Fail(PK_MI355_E_DEVICE, "HIP failure in pk_decodable_init: %s", hipGetErrorString(e)); };
-  if (ScoreSingleQueue(am, feats, true, prob_scale)) return;
-  float *host = static_cast<float *>(malloc(sizeof(float) * (size_t)T * N));   // util.cc:58-68 pk_alloc
+  // One copy behind the last kernel.  The 12 MB of a 10 s utterance cross the link in 0.22 ms (54 GB/s, into pageable
+  // malloc() memory as fast as into page-locked memory) -- more than the network takes (0.17 ms); sending the
+  // log-likelihoods in row blocks under the last layer's remaining blocks was built three ways and gains nothing
+  // (tools/experiments/init_pipeline, profiles/r04_decodable_init_pipeline.txt).
+  const size_t bytes = sizeof(float) * (size_t)T * N;
+  float *host = static_cast<float *>(malloc(bytes));                              // util.cc:58-68 pk_alloc
   if (!host) { Fail(PK_MI355_E_INVALID, "out of host memory"); return; }
-  hipError_t e = hipMemcpyAsync(host, w->d_out, sizeof(float) * (size_t)T * N, hipMemcpyDeviceToHost, w->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
-  if (e != hipSuccess) { free(host); dev_fail(e); return; }
-  if (f16) {                      // an operand left the fp16 split's range: fail loudly, deliver nothing
+  int rc = ScoreSingleQueue(am, feats, true, prob_scale);
+  hipError_t e = hipSuccess;
+  if (!rc) e = hipMemcpyAsync(host, w->d_out, bytes, hipMemcpyDeviceToHost, w->stream);
+  const hipError_t se = hipStreamSynchronize(w->stream);      // (drained whatever happened: `host` may be freed next)
+  if (e == hipSuccess) e = se;
+  if (!rc && e != hipSuccess) { dev_fail(e); rc = PK_MI355_E_DEVICE; }
+  if (!rc && f16) {                 // an operand left the fp16 split's range: fail loudly, deliver nothing
     const ExecBufs *eb = &w->exec;
-    if (EvalRange(am, &eb, 1)) { free(host); return; }
+    rc = EvalRange(am, &eb, 1);
   }
+  if (rc) { free(host); return; }
   self->log_prob.ncol = T;
   self->log_prob.nrow = N;
   self->log_prob.data = host;

@@ -889,6 +889,37 @@ def test_view_destroyed_after_its_batch_is_safe():
         L_.pk_decodable_destroy(C.byref(fresh[u]))       # the last of these releases the arena
     for u in range(3):
         L_.pk_decodable_destroy(C.byref(late[u]))        # views of a generation that is gone: a no-op, not a free()
+    # the copy of a destroyed view is destroyed only after the generation's record has been
+    # recycled for a LATER fetch_all (records are reused once 64 more have been retired): it must not count
+    # against the generation that now lives in that record
+    bs4 = pk.BatchScorer(am, synth.global_cmvn_stats(), 3, sum(len(w) for w in waves[:3]))
+    bs4.set_waves(waves[:3])
+    bs4.score(0.1)
+    first = (pk.pk_decodable_t * 3)()
+    assert L_.pk_mi355_batch_fetch_all(bs4._h, first, 3, 1) == 0
+    ghosts = (pk.pk_decodable_t * 3)()
+    for u in range(3):
+        ghosts[u].log_prob.ncol, ghosts[u].log_prob.nrow, ghosts[u].log_prob.data, ghosts[u].am = (
+            first[u].log_prob.ncol, first[u].log_prob.nrow, first[u].log_prob.data, first[u].am)
+        L_.pk_decodable_destroy(C.byref(first[u]))
+    handles = set()
+    cur = (pk.pk_decodable_t * 3)()
+    for i in range(200):
+        assert L_.pk_mi355_batch_fetch_all(bs4._h, cur, 3, 1) == 0
+        handles.add(cur[0].am & ~63)
+        if i < 199:
+            for u in range(3):
+                L_.pk_decodable_destroy(C.byref(cur[u]))
+    assert (ghosts[0].am & ~63) in handles and ghosts[0].am != cur[0].am      # the record WAS recycled; the serial moved on
+    for u in range(3):
+        L_.pk_decodable_destroy(C.byref(ghosts[u]))      # three ghost destroys: ignored
+    L_.pk_mi355_batch_destroy(bs4._h)
+    bs4._h = None
+    for u in range(3):                                   # the current generation still owns the arena
+        lp = cur[u].log_prob
+        assert bits_equal(np.ctypeslib.as_array(lp.data, shape=(lp.ncol, lp.nrow)), want[u])
+    for u in range(3):
+        L_.pk_decodable_destroy(C.byref(cur[u]))
     # Python mirror: closing the scorer while views are alive, views die later
     bs2 = pk.BatchScorer(am, synth.global_cmvn_stats(), 3, sum(len(w) for w in waves[:3]))
     bs2.set_waves(waves[:3])
@@ -1143,3 +1174,4 @@ def test_fuzz_batches_wide_model_both_precisions(seed, monkeypatch):
                 assert bits_equal(got, ll), "dims %s utt %d" % (dims, u)
             else:
                 assert_loglik_close(got, ll)
+
