@@ -327,6 +327,17 @@ def oracle_errors_wide(sample):
     return {m: float(np.max(np.abs(sample[m].astype(np.float64) - ref) / den)) for m in ("f16x3", "f16")}
 
 
+def f16_kernel_label(precision):
+    """Which kernel a precision mode runs (gemm_f16.hip: LaunchGemmF16; PK_MI355_F16_SHAPE forces a form for A/B runs)."""
+    if precision == "f32":
+        return "GemmKernel (fp32 MFMA affine layers, %d launches/step)"
+    forced = os.environ.get("PK_MI355_F16_SHAPE", "")
+    k32 = forced == "16" or (forced != "32" and precision == "f16x3")
+    name = "GemmF16K32Kernel (v_mfma_f32_16x16x32_f16" if k32 else "GemmF16Kernel (v_mfma_f32_32x32x16_f16"
+    terms = "3 MFMA per algorithmic product" if precision == "f16x3" else "1 MFMA per product, plain fp16 operands"
+    return name + ", " + terms + ", %d launches/step)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -405,6 +416,36 @@ def main():
         chk.close()
         replica_check = "passed"
 
+    # ---- the C entry of the same collective: with a real RCCL group, an ncclComm_t of our
+    # own over all ranks (ctypes on torch's RCCL; the id shared by one small broadcast), pk_mi355_am_broadcast_from
+    # into a second, zero-initialised model on every rank, and that model's scores compared across ranks and with
+    # the root's real model.  Before the timed region; no new process.
+    c_abi_broadcast = "not run (no process group)"
+    if tdist.is_initialized():
+        if args.backend != "nccl":
+            c_abi_broadcast = "skipped: gloo rehearsal (two RCCL ranks cannot share one device; the C entry runs over a real communicator at nranks = 1 in tests/)"
+        else:
+            zl = [(l[0], np.zeros_like(l[1]), np.zeros_like(l[2])) if l[0] == "linear" else l for l in layers]
+            am_z = pk.AcousticModel(zl, np.full_like(prior, 1.0), L, R, precision=args.precision).set_softmax(args.softmax)
+            binding, comm = pkdist.make_rccl_comm(rank, world, cdev)
+            try:
+                am_z.broadcast(comm, root=0, src=am)          # on the root the bytes sent are `am`'s; everyone receives into am_z
+            finally:
+                binding.comm_destroy(comm)
+
+            def probe(model):
+                c = pk.BatchScorer(model, synth.global_cmvn_stats(), 1, 16000)
+                c.set_waves([synth.utterance(0, 1.0)])
+                c.score(0.1)
+                v = float(np.sum(c.fetch(0).log_prob().astype(np.float64)))
+                c.close()
+                return v
+            sz, sa = probe(am_z), probe(am)
+            if not (sz == sa and pkdist.all_ranks_agree(sz, cdev)):
+                raise SystemExit("pk_mi355_am_broadcast (C ABI) mismatch: rank %d scores %r, expected %r" % (rank, sz, sa))
+            am_z.close()
+            c_abi_broadcast = "passed"
+
     def timed_steps(scorer):
         """W untimed + K timed passes bracketed by barrier + device sync.  The per-kernel HIP events
         (two per launch, ~0.13 ms per step of dispatch gaps) are recorded on the LAST timed pass
@@ -424,9 +465,12 @@ def main():
         elapsed = time.perf_counter() - t0
         tm_ = scorer.timing()
         scorer.enable_timing(False)
+        timed_steps.own_elapsed = elapsed
         return pkdist.max_over_ranks(elapsed, cdev), tm_
 
     dt, tm = timed_steps(bs)
+    # every rank's own rate over ITS barrier-to-barrier time (stragglers show as a low minimum)
+    rank_lo, rank_hi = pkdist.min_max_over_ranks(frames_per_step * args.steps / timed_steps.own_elapsed, cdev)
     total_frames = pkdist.sum_over_ranks(frames_per_step, cdev)
 
     # ---- supplementary: the same workload in the other precision mode (same K, W)
@@ -485,10 +529,12 @@ def main():
                        "parallelism": "utterance-sharded x%d, weights broadcast once (%s)" % (
                            world, "RCCL" if args.backend == "nccl" else "gloo rehearsal"),
                        "collective": {"backend": args.backend, "process_group": bool(tdist.is_initialized()),
-                                      "replica_check": replica_check}},
+                                      "replica_check": replica_check, "c_abi_broadcast": c_abi_broadcast},
+                       "per_rank_frames_per_s": {"min": rank_lo, "max": rank_hi,
+                                                 "note": "each rank's own frames over its own barrier-to-barrier time; "
+                                                         "value = all ranks' frames over the slowest rank's time"}},
             "roofline": {"bound": "mfma",
-                         "kernel": ("GemmKernel (fp32 MFMA affine layers, %d launches/step)" if args.precision == "f32" else
-                                    "GemmF16Kernel (fp16 MFMA, 3 MFMA per algorithmic product, %d launches/step)") % gemm_launches,
+                         "kernel": f16_kernel_label(args.precision) % gemm_launches,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
                          "flop_per_frame": am.flops_per_frame(),

@@ -126,7 +126,10 @@ def _build_locked(verbose):
 
 
 if __name__ == "__main__":
-    if "--hashes" in sys.argv:          # tools/profile_gpu.sh: what the profiled library was built from
-        print("library_build_hash=%s gemm_source_hash=%s" % (source_hash()[:16], gemm_source_hash()))
+    if "--hashes" in sys.argv:          # tools/profile_gpu.sh: what the profiled library was built from, and the
+        # library FILE that will be loaded (tools/ab_so.sh swaps prebuilt libraries under a matching stamp: ADVICE round 3)
+        with open(LIB, "rb") as f:
+            file_sha = hashlib.sha256(f.read()).hexdigest()[:16]
+        print("library_build_hash=%s gemm_source_hash=%s library_file_sha256=%s" % (source_hash()[:16], gemm_source_hash(), file_sha))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

@@ -449,6 +449,10 @@ __global__ __launch_bounds__(64 * (kXProducers + 1)) void TailExactKernel(
 // it to the running sums (lane = row; the sums travel from duty wave to duty wave through LDS; one
 // barrier per tile).  Then every wave finishes its own registers: e / sum, floor, logf, prior, scale --
 // one read of the logits, one expf, one write: 24 kB/frame instead of 36.
+// Resources (hipcc -Rpass-analysis=kernel-resource-usage, ROCm 7.2): 115 (probabilities) / 121
+// (log-likelihoods) VGPRs of the 128 a 1024-thread workgroup may use, 0 AGPRs, ScratchSize 0 -- e[] does not
+// spill; 20 / 24 SGPRs are spilled to VGPR lanes (no memory traffic).  Rows of 3 009 columns and more take
+// TailExactKernel (the switch-over is a test case: N = 3008 | 3009).
 constexpr int kRegTiles = 47;                          // 47 x 64 = 3 008 columns at most
 constexpr int kRegWaves = 16;
 constexpr int kRegRows = 2 * kRegWaves;                // rows per workgroup

@@ -6,6 +6,7 @@ the only exchange is ONE broadcast of the packed weight blob at load (RCCL over 
 on GPUs; ``backend="nccl"`` is RCCL on ROCm).  These helpers are backend-agnostic
 so the same code is exercised with ``gloo`` on CPU in tests/test_dist_gloo.py.
 """
+import ctypes as C
 import os
 
 import torch
@@ -104,3 +105,98 @@ def broadcast_model(am, device, src=0):
     ptr, nbytes = am.blob()
     broadcast_blob(alias_device_bytes(ptr, nbytes, device), src=src)
     torch.cuda.synchronize(device)
+
+
+# ---- an ncclComm_t of our own, through ctypes on the RCCL copy ALREADY LOADED in the process (torch's), so that a
+# multi-rank run exercises the C entry pk_mi355_am_broadcast as well as the torch.distributed path (VERDICT round 3,
+# next #4).  rccl.h: ncclGetUniqueId(ncclUniqueId *), ncclCommInitRank(ncclComm_t *, int nranks, ncclUniqueId id
+# BY VALUE, int rank), ncclCommDestroy(ncclComm_t), ncclGetErrorString(ncclResult_t); NCCL_UNIQUE_ID_BYTES = 128.
+
+NCCL_UNIQUE_ID_BYTES = 128
+
+
+class NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * NCCL_UNIQUE_ID_BYTES)]
+
+
+def loaded_rccl_path():
+    """Path of the librccl mapped into this process (torch loads its own copy for backend "nccl"), or None."""
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(" ", 1)[-1].strip()
+                if "librccl" in os.path.basename(path):
+                    return path
+    except OSError:
+        pass
+    return None
+
+
+class RcclBinding:
+    """The four RCCL entry points the C-ABI check needs, bound with ctypes.  `path`: the library file (dlopen of a
+    file that is already mapped returns that copy -- one RCCL per process, as pk_mi355_am_broadcast requires)."""
+
+    def __init__(self, path=None):
+        path = path or os.environ.get("PK_MI355_RCCL_LIB") or loaded_rccl_path()
+        if not path:
+            raise RuntimeError("no RCCL is loaded in this process (init a torch.distributed nccl group first, "
+                               "or name the library in PK_MI355_RCCL_LIB)")
+        self.path = path
+        self.lib = C.CDLL(path)
+        self.lib.ncclGetUniqueId.argtypes = [C.POINTER(NcclUniqueId)]
+        self.lib.ncclGetUniqueId.restype = C.c_int
+        self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, NcclUniqueId, C.c_int]
+        self.lib.ncclCommInitRank.restype = C.c_int
+        self.lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        self.lib.ncclCommDestroy.restype = C.c_int
+        self.lib.ncclGetErrorString.argtypes = [C.c_int]
+        self.lib.ncclGetErrorString.restype = C.c_char_p
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %s" % (what, self.lib.ncclGetErrorString(rc).decode()))
+
+    def unique_id(self):
+        uid = NcclUniqueId()
+        self._check(self.lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        return C.string_at(C.addressof(uid), NCCL_UNIQUE_ID_BYTES)
+
+    def comm_init_rank(self, nranks, uid_bytes, rank):
+        if len(uid_bytes) != NCCL_UNIQUE_ID_BYTES:
+            raise ValueError("ncclUniqueId is %d bytes" % NCCL_UNIQUE_ID_BYTES)
+        uid = NcclUniqueId()
+        C.memmove(C.addressof(uid), uid_bytes, NCCL_UNIQUE_ID_BYTES)
+        comm = C.c_void_p()
+        self._check(self.lib.ncclCommInitRank(C.byref(comm), int(nranks), uid, int(rank)), "ncclCommInitRank")
+        return comm.value
+
+    def comm_destroy(self, comm):
+        self._check(self.lib.ncclCommDestroy(C.c_void_p(comm)), "ncclCommDestroy")
+
+
+def share_bytes(payload, n, src=0, device="cpu"):
+    """`n` bytes from rank `src` to every rank through the process group (the ncclUniqueId hand-shake)."""
+    t = torch.zeros(n, dtype=torch.uint8, device=device)
+    if payload is not None:
+        t.copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(t, src=src)
+    return bytes(t.cpu().numpy().tobytes())
+
+
+def make_rccl_comm(rank, world, device="cpu", binding=None):
+    """(binding, ncclComm_t) over all ranks of the job: rank 0 draws the id, one small broadcast shares it,
+    every rank joins.  No new process, nothing re-executed."""
+    b = binding or RcclBinding()
+    os.environ.setdefault("PK_MI355_RCCL_LIB", b.path)    # libpk_mi355 binds ncclBroadcast in the same copy (capi.hip: BindRccl)
+    uid = share_bytes(b.unique_id() if rank == 0 else None, NCCL_UNIQUE_ID_BYTES, 0, device)
+    return b, b.comm_init_rank(world, uid, rank)
+
+
+def min_max_over_ranks(value, device="cpu"):
+    lo = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    hi = lo.clone()
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return float(lo.item()), float(hi.item())

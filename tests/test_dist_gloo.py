@@ -42,13 +42,72 @@ def _worker(rank, world, port, out_dir):
     # timing protocol: max over ranks of the elapsed time, sum over ranks of the frames
     assert pkdist.max_over_ranks(1.0 + rank) == float(world)
     assert pkdist.sum_over_ranks(998 * 5) == 998 * 5 * world
+    assert pkdist.min_max_over_ranks(10.0 * (rank + 1)) == (10.0, 10.0 * world)      # per-rank rates in the bench line
+    # the ncclUniqueId hand-shake of the C-ABI broadcast check: rank 0's 128 bytes reach every rank
+    uid = bytes(range(128)) if rank == 0 else None
+    assert pkdist.share_bytes(uid, 128, src=0) == bytes(range(128))
+    # ... and the communicator is made from them on every rank, through the ctypes binding (a fake RCCL here)
+    fake = os.path.join(out_dir, "libfakerccl.so")
+    binding, comm = pkdist.make_rccl_comm(rank, world, "cpu", pkdist.RcclBinding(fake))
+    assert comm == 0x5000 + 16 * world + rank
+    binding.comm_destroy(comm)
     pkdist.barrier()
     open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     pkdist.shutdown()
 
 
+FAKE_RCCL = r"""
+/* a stand-in for librccl's four entry points, to test the ctypes binding (argument types, the 128-byte
+   ncclUniqueId passed BY VALUE) without a GPU */
+#include <string.h>
+typedef struct { char internal[128]; } ncclUniqueId;
+static int id_ok(const ncclUniqueId *u) { for (int i = 0; i < 128; ++i) if ((unsigned char)u->internal[i] != (unsigned char)(i * 7 + 3)) return 0; return 1; }
+int ncclGetUniqueId(ncclUniqueId *u) { for (int i = 0; i < 128; ++i) u->internal[i] = (char)(i * 7 + 3); return 0; }
+int ncclCommInitRank(void **comm, int nranks, ncclUniqueId id, int rank) {
+  if (!id_ok(&id)) return 4;                       /* ncclInvalidArgument */
+  if (rank < 0 || rank >= nranks) return 4;
+  *comm = (void *)(long)(0x5000 + 16 * nranks + rank);
+  return 0;
+}
+int ncclCommDestroy(void *comm) { return ((long)comm & ~0xffL) == 0x5000 ? 0 : 5; }
+const char *ncclGetErrorString(int r) { return r == 4 ? "invalid argument (fake)" : r == 5 ? "invalid usage (fake)" : "?"; }
+"""
+
+
+def _build_fake_rccl(dirname):
+    import subprocess
+    src = os.path.join(dirname, "fakerccl.c")
+    open(src, "w").write(FAKE_RCCL)
+    lib = os.path.join(dirname, "libfakerccl.so")
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", src, "-o", lib])
+    return lib
+
+
+def test_rccl_ctypes_binding_against_a_fake_library(tmp_path):
+    """pocketkaldi_amd.dist.RcclBinding is what bench.py uses at N > 1 to make the ncclComm_t it hands to
+    pk_mi355_am_broadcast: the binding -- signatures, struct by value, error strings --
+    is checked here against a library with RCCL's symbol table; the real library is used on the GPU box."""
+    b = pkdist.RcclBinding(_build_fake_rccl(str(tmp_path)))
+    uid = b.unique_id()
+    assert uid == bytes((i * 7 + 3) & 0xFF for i in range(128))
+    assert b.comm_init_rank(8, uid, 5) == 0x5000 + 16 * 8 + 5
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        b.comm_init_rank(8, bytes(128), 5)                 # another id: the fake checks what arrived by value
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        b.comm_init_rank(2, uid, 2)
+    with pytest.raises(ValueError):
+        b.comm_init_rank(2, uid[:100], 0)
+    b.comm_destroy(0x5000 + 16 * 8 + 5)
+    with pytest.raises(RuntimeError, match="invalid usage"):
+        b.comm_destroy(0x77)
+    # the copy torch maps at import (its own, bundled) is the one a real run binds to -- found without loading anything
+    found = pkdist.loaded_rccl_path()
+    assert found and os.path.exists(found) and "librccl" in os.path.basename(found)
+
+
 def test_world2_gloo(tmp_path):
     world = 2
+    _build_fake_rccl(str(tmp_path))
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))
 

@@ -678,7 +678,7 @@ def _bits_equal_nan(a, b):
                                                  np.where(both_nan, 0, b.view(np.uint32)))
 
 
-@pytest.mark.parametrize("T,N", [(1, 50), (63, 64), (64, 65), (129, 3000), (70, 8000)])
+@pytest.mark.parametrize("T,N", [(1, 50), (63, 64), (64, 65), (129, 3000), (33, 3008), (33, 3009), (70, 8000)])   # 3008 | 3009: register kernel | two-pass kernel
 def test_reference_softmax_probabilities_bit_exact(T, N):
     rng = np.random.default_rng(T + N)
     W = (rng.standard_normal((N, 48)) * 0.4).astype(np.float32)

@@ -5,6 +5,7 @@ cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/ab_so.txt
 : > $OUT
 cp pocketkaldi_amd/libpk_mi355.so /tmp/keep.so
+trap 'cp /tmp/keep.so pocketkaldi_amd/libpk_mi355.so' EXIT      # an interrupted A/B must not leave a swapped library under the tree's stamp
 for rep in 1 2; do
 for v in new old; do
   cp gpurun_ab/$v.so pocketkaldi_amd/libpk_mi355.so
