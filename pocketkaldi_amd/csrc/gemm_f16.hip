@@ -38,6 +38,7 @@
 #include <hip/hip_fp16.h>
 
 #include "pk_dma.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <mutex>
 
@@ -156,14 +157,15 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
   const long long st_kernel = __builtin_amdgcn_s_memtime();
 #endif
 
-  // XCD-aware tile walk, as in gemm.hip: contiguous ids per XCD, 4 x 4 super-tiles
+  // XCD-aware tile walk, as in gemm.hip: contiguous ids per XCD, walk_m x walk_n (4 x 4) super-tiles
   const int nblk = gridDim.x;                       // multiple of 8
   const int b = blockIdx.x;
   const int wg = (b % 8) * (nblk / 8) + b / 8;
-  const int super_m = (a.tiles_m + 3) / 4;
-  const int s = wg / 16, w = wg % 16;
-  const int tm = (s % super_m) * 4 + (w % 4);
-  const int tn = (s / super_m) * 4 + (w / 4);
+  const int super_m = (a.tiles_m + a.walk_m - 1) / a.walk_m;
+  const int per = a.walk_m * a.walk_n;
+  const int s = wg / per, w = wg % per;
+  const int tm = (s % super_m) * a.walk_m + (w % a.walk_m);
+  const int tn = (s / super_m) * a.walk_n + (w / a.walk_m);
   if (tm >= a.tiles_m || tn >= a.tiles_n) return;
   const int m0 = tm * kT, n0 = tn * kT;
 
@@ -442,13 +444,16 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a
   const long long st_kernel = __builtin_amdgcn_s_memtime();
 #endif
 
+  // XCD-aware tile walk: workgroup ids are made contiguous per XCD and walk walk_m x walk_n super-tiles (4 x 4: the
+  // 32 workgroups resident on an XCD then cover 8 x 4 tiles and share 8 X and 4 W panels in that XCD's L2)
   const int nblk = gridDim.x;                       // multiple of 8
   const int b = blockIdx.x;
   const int wg = (b % 8) * (nblk / 8) + b / 8;
-  const int super_m = (a.tiles_m + 3) / 4;
-  const int s = wg / 16, w = wg % 16;
-  const int tm = (s % super_m) * 4 + (w % 4);
-  const int tn = (s / super_m) * 4 + (w / 4);
+  const int super_m = (a.tiles_m + a.walk_m - 1) / a.walk_m;
+  const int per = a.walk_m * a.walk_n;
+  const int s = wg / per, w = wg % per;
+  const int tm = (s % super_m) * a.walk_m + (w % a.walk_m);
+  const int tn = (s / super_m) * a.walk_n + (w / a.walk_m);
   if (tm >= a.tiles_m || tn >= a.tiles_n) return;
   const int m0 = tm * kT, n0 = tn * kT;
 
@@ -740,8 +745,15 @@ void LaunchGemmF16(const GemmF16Args &a_in, hipStream_t stream) {
   if (!a.e_w) a.e_w = ZeroWord();
   if (!a.e_in) a.e_in = ZeroWord();
   if (!a.e_out) a.e_out = ZeroWord();
-  const int super_m = (a.tiles_m + 3) / 4, super_n = (a.tiles_n + 3) / 4;
-  const int nblk = super_m * super_n * 16;
+  // PK_MI355_F16_WALK=MxN: the super-tile shape of the 16x16x32 kernel's tile walk, a measurement switch
+  // (profiles/r04_f16_walk_ab.txt).  The grid is rounded up to a multiple of 8 (one share per XCD); ids past the
+  // last super-tile fall outside the tile range and return at once.
+  static const int walk[2] = {[] { const char *e = getenv("PK_MI355_F16_WALK"); int m = 4, n = 4; if (e) sscanf(e, "%dx%d", &m, &n); return m > 0 && m <= 64 ? m : 4; }(),
+                              [] { const char *e = getenv("PK_MI355_F16_WALK"); int m = 4, n = 4; if (e) sscanf(e, "%dx%d", &m, &n); return n > 0 && n <= 64 ? n : 4; }()};
+  a.walk_m = walk[0];
+  a.walk_n = walk[1];
+  const int super_m = (a.tiles_m + a.walk_m - 1) / a.walk_m, super_n = (a.tiles_n + a.walk_n - 1) / a.walk_n;
+  const int nblk = (super_m * super_n * a.walk_m * a.walk_n + 7) / 8 * 8;
   dim3 grid(nblk), block(kThreadsF16);
   const size_t lds = kRingF16 * kHalfSlabBytes;
   // the 128 KiB dynamic-LDS opt-in is a per-DEVICE function attribute: set it once for every device a

@@ -101,6 +101,7 @@ struct GemmF16Args {
   int64_t ldo;           // floats (out_f32) or halves (out)
   int tiles_m, tiles_n;  // 256 x 256 tiles
   int terms = 3;         // 3: hi hi + hi lo + lo hi (f16x3); 1: hi hi only (plain fp16 operands)
+  int walk_m = 4, walk_n = 4;   // super-tile shape of the 16x16x32 kernel's tile walk (set by LaunchGemmF16)
   // Power-of-two operand scaling (device words, part of the model blob so that the one broadcast carries
   // them): the operands hold X * 2^e_in and W * 2^e_w; the epilogue undoes both and applies the exponent of
   // the NEXT layer's operand, 2^e_out, to what it writes as (hi, lo) halves (e_out points at a zero word for
