@@ -557,8 +557,8 @@ def main():
             out["stage_roofline"][k] = {"bound": "hbm", "bytes_per_frame": bpf, "achieved": gbs,
                                         "peak": hbm_peak, "unit": "GB/s", "frac": gbs / hbm_peak}
         # SURVEY 8(d) prices the front-end against HBM by contract; what limits it in practice (PMC):
-        out["stage_roofline"]["fbank"]["limited_by"] = "LDS pipe (profiles/r02_fbank_lds.txt, DESIGN.md 3.2)"
-        out["stage_roofline"]["cmvn"]["limited_by"] = "the serial window-sum recurrence, one rounding per frame (DESIGN.md 3.3)" 
+        out["stage_roofline"]["fbank"]["limited_by"] = "LDS pipe (profiles/r02_fbank_lds.txt, DESIGN.md 3.3)"
+        out["stage_roofline"]["cmvn"]["limited_by"] = "the serial window-sum recurrence, one rounding per frame (DESIGN.md 3.4)"
         if args.model == "S" and args.batch == 256 and gemm_launches and args.precision == "f32":
             traffic, source = measured_traffic()
             out["roofline"]["traffic"] = traffic
