@@ -424,6 +424,8 @@ def main():
     if tdist.is_initialized():
         if args.backend != "nccl":
             c_abi_broadcast = "skipped: gloo rehearsal (two RCCL ranks cannot share one device; the C entry runs over a real communicator at nranks = 1 in tests/)"
+        elif os.environ.get("PK_BENCH_SKIP_C_ABI", "") == "1":
+            c_abi_broadcast = "skipped: PK_BENCH_SKIP_C_ABI=1"
         else:
             zl = [(l[0], np.zeros_like(l[1]), np.zeros_like(l[2])) if l[0] == "linear" else l for l in layers]
             am_z = pk.AcousticModel(zl, np.full_like(prior, 1.0), L, R, precision=args.precision).set_softmax(args.softmax)

@@ -271,7 +271,7 @@ inline const int32_t *ExpX(const pk_mi355_am *am, int l) { return ExpBase(am) + 
 inline const int32_t *ExpZero(const pk_mi355_am *am) { return ExpBase(am) + 2 * am->lin.size(); }
 inline uint32_t *RangeOf(const ExecBufs &e, int l) { return e.range ? e.range + (size_t)l * kRangeSlots : nullptr; }
 
-constexpr int kMaxXExp = 30;                     // |operand exponent| (|w_exp| <= 40: 2^(e_out - e_in - e_w) stays a normal float)
+constexpr int kMaxXExp = 30;                     // |operand exponent| (|w_exp| <= 60: 2^(e_out - e_in - e_w) stays a normal float)
 constexpr float kRangeSaturated = 65504.0f;      // the split clamps here (gemm_f16.hip: Split)
 constexpr float kRangeTooSmall = 0.03125f;       // 2^-5: below this every lo half of the operand is an fp16 subnormal
                                                  // (|lo| <= 2^-12 |x|), and the mode degrades towards plain fp16
@@ -911,7 +911,7 @@ int pk_mi355_am_finalize(pk_mi355_am_t *am, const float *prior, int num_pdfs, in
       // PK_MI355_NO_PRESCALE=1: measurement switch only (what the prescale costs in clock: normal lo halves toggle
       // more bits than subnormal ones, and this mode is power-limited) -- never set it in production
       static const bool no_prescale = [] { const char *e = getenv("PK_MI355_NO_PRESCALE"); return e && atoi(e) != 0; }();
-      const int w_exp = (wmax > 0.0f && !no_prescale) ? std::min(40, std::max(-40, 13 - ilogbf(wmax))) : 0;
+      const int w_exp = (wmax > 0.0f && !no_prescale) ? std::min(60, std::max(-60, 13 - ilogbf(wmax))) : 0;
       am->h_exps[li - 1] = w_exp;
       const float w_scale = ldexpf(1.0f, w_exp);
       _Float16 *w2 = reinterpret_cast<_Float16 *>(blob.data() + D.wt_off);
@@ -1393,19 +1393,23 @@ int pk_mi355_am_set_input_exponents(pk_mi355_am_t *am, const int32_t *x_exp, int
 }  // extern "C"
 
 namespace {
-// One calibration decision from the range words of one pass (h_range of `e`, stream synchronised): the first
-// operand whose scaled maximum lies outside [2^9, 2^12) gets a new exponent that puts it into [2^10, 2^11) --
-// 32 x headroom below the clamp, 2^15 above the subnormal-lo threshold; a saturated one (true maximum unknown)
-// comes down by 2^12.  Later operands were computed from it, so the caller reruns before looking further.
-// Returns 1 if an exponent changed, 0 if every operand is in band.
-int CalibrateStep(pk_mi355_am *am, const ExecBufs &e) {
+// One calibration decision from the range words of one pass (h_range of `e`, stream synchronised).  Operands are
+// settled front to back: the first operand not yet settled gets the CANONICAL exponent for its measured maximum --
+// the one that puts it into [2^10, 2^11): 32 x headroom below the clamp, 2^15 above the subnormal-lo threshold --
+// whatever exponent it started from, so that a calibration depends on the network and the data only (a saturated
+// operand, true maximum unknown, first comes down by 2^12 and is looked at again).  Later operands were computed
+// from it, so the caller reruns before looking further.  An operand already settled in this calibration is left
+// alone while it stays inside [2^9, 2^12) (the maxima move in the last bits when an earlier exponent changes).
+// Returns 1 if an exponent changed, 0 if every operand is settled.
+int CalibrateStep(pk_mi355_am *am, const ExecBufs &e, std::vector<char> *settled) {
   const int nlin = (int)am->lin.size();
   for (int l = 0; l < nlin; ++l) {
     const float m = RangeMax(e, l);
     int32_t &xe = am->h_exps[nlin + l];
     int want = xe;
     if (m >= kRangeSaturated) want = xe - 12;
-    else if (m > 0.0f && (m < 512.0f || m >= 4096.0f)) want = xe + 10 - ilogbf(m);
+    else if (m > 0.0f && (!(*settled)[l] || m < 512.0f || m >= 4096.0f)) { want = xe + 10 - ilogbf(m); (*settled)[l] = 1; }
+    else (*settled)[l] = 1;                        // an all-zero operand carries nothing to place
     want = std::min(kMaxXExp, std::max(-kMaxXExp, want));
     if (want != xe) { xe = want; return 1; }
   }
@@ -1428,10 +1432,14 @@ int pk_mi355_am_calibrate(pk_mi355_am_t *am, const pk_matrix_t *feats) {
   if (am->exps_stale && (rc = RefreshExps(am))) return rc;
   Workspace *w = am->ws;
   const int max_passes = 6 * (int)am->lin.size() + 8;
+  std::vector<char> settled(am->lin.size(), 0);
   for (int pass = 0; pass < max_passes; ++pass) {
     if ((rc = ScoreSingleQueue(am, feats, false, 1.0f))) return rc;
     HIP_TRY(hipStreamSynchronize(w->stream));
-    if (!CalibrateStep(am, w->exec)) return 0;
+    if (!CalibrateStep(am, w->exec, &settled)) {
+      const ExecBufs *eb = &w->exec;               // settled: what this last pass wrote must be in range (an operand
+      return EvalRange(am, &eb, 1);                // pinned at the exponent limit is reported, not accepted)
+    }
     if ((rc = UploadExps(am))) return rc;
   }
   return Fail(PK_MI355_E_RANGE, "calibration did not settle in %d passes", max_passes);
@@ -1756,6 +1764,7 @@ int pk_mi355_batch_calibrate(pk_mi355_batch_t *b) {
   std::lock_guard<std::mutex> lock(am->mu);
   if (am->exps_stale && (rc = RefreshExps(am))) return rc;
   const int max_passes = 6 * (int)am->lin.size() + 8;
+  std::vector<char> settled(am->lin.size(), 0);
   for (int pass = 0; pass < max_passes; ++pass) {
     rc = pk_mi355_batch_score(b, 1.0f, 0);
     b->scored = false;                           // calibration passes are not results
@@ -1764,7 +1773,10 @@ int pk_mi355_batch_calibrate(pk_mi355_batch_t *b) {
     HIP_TRY(hipStreamSynchronize(b->stream));
     if (b->lanes == 2)
       for (int i = 0; i < b->exec.range_words; ++i) b->exec.h_range[i] = std::max(b->exec.h_range[i], b->exec2.h_range[i]);
-    if (!CalibrateStep(am, b->exec)) return 0;
+    if (!CalibrateStep(am, b->exec, &settled)) {
+      const ExecBufs *eb = &b->exec;
+      return EvalRange(am, &eb, 1);
+    }
     if ((rc = UploadExps(am))) return rc;
   }
   return Fail(PK_MI355_E_RANGE, "calibration did not settle in %d passes", max_passes);

@@ -208,3 +208,54 @@ def test_the_broadcast_carries_the_calibration():
     for a, b in zip(other.exponents(), am.exponents()):
         assert list(a) == list(b)
     assert np.array_equal(pk.Decodable(other, 0.1, feats).log_prob(), want)
+
+
+def _fuzz_seeds(n):
+    import os
+    base = int(os.environ.get("PK_FUZZ_BASE", "0"))
+    return range(base, base + int(os.environ.get("PK_FUZZ_SEEDS", n)))
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds(8))
+def test_fuzz_rescaled_networks_calibrate_onto_the_same_grid(seed):
+    """Random ReLU networks, every hidden activation moved by a random power of two (h_i' = h_i 2^k_i: W_i' = W_i
+    2^(k_i - k_(i-1)), b_i' = b_i 2^k_i; the logits stay): the same network in fp32, bit for bit in the oracle.  After
+    calibration the split-fp16 operands of the rescaled network ARE those of the original (w_exp absorbs the weight
+    scale, x_exp the activation scale, both exact), so f16x3 returns the same bits for both -- and both sit inside
+    2e-5 of the oracle.  Uncalibrated, a network pushed far enough either way must fail loudly, never quietly."""
+    rng = np.random.default_rng(0xCA1B + seed)
+    nh = int(rng.integers(1, 4))
+    dims = [440] + [int(rng.integers(48, 400)) for _ in range(nh)] + [int(rng.integers(30, 700))]
+    layers = []
+    for i in range(len(dims) - 1):
+        W = (rng.standard_normal((dims[i + 1], dims[i])) * np.sqrt(2.0 / dims[i])).astype(np.float32)
+        b = (rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32)
+        layers.append(("linear", W, b))
+        layers.append(("relu",) if i < len(dims) - 2 else ("softmax",))
+    prior = rng.uniform(0.5, 1.5, dims[-1])
+    prior = (prior / prior.sum()).astype(np.float32)
+    k = [0] + [int(rng.integers(-12, 13)) for _ in range(nh)] + [0]
+    moved, li = [], 0
+    for l in layers:
+        if l[0] == "linear":
+            moved.append(("linear", l[1] * np.float32(2.0 ** (k[li + 1] - k[li])), l[2] * np.float32(2.0 ** k[li + 1])))
+            li += 1
+        else:
+            moved.append(l)
+    feats = _feats(0.6, 40 + seed)
+    ref = O.Nnet(layers).am_compute(feats, prior, 5, 5, 0.1)
+    assert np.array_equal(ref, O.Nnet(moved).am_compute(feats, prior, 5, 5, 0.1))
+    am0 = pk.AcousticModel(layers, prior, 5, 5, precision="f16x3").calibrate(feats)
+    am1 = pk.AcousticModel(moved, prior, 5, 5, precision="f16x3")
+    try:
+        quiet = pk.Decodable(am1, 0.1, feats).log_prob()          # in range by luck of the draw: then it must be accurate
+        assert _rel_err(quiet, ref) < 1e-4
+    except pk.PkError as e:
+        assert "range" in str(e)
+    am1.calibrate(feats)
+    (w0, x0), (w1, x1) = am0.exponents(), am1.exponents()
+    assert list(x1 - x0) == [-kk for kk in k[:-1]], (k, x0, x1)
+    assert list(w1 - w0) == [k[i] - k[i + 1] for i in range(len(k) - 1)]
+    got0, got1 = pk.Decodable(am0, 0.1, feats).log_prob(), pk.Decodable(am1, 0.1, feats).log_prob()
+    assert np.array_equal(got0, got1)
+    assert _rel_err(got1, ref) < 2e-5
