@@ -6,7 +6,7 @@
 mkdir -p gpurun_out
 SEL='fuzz and not fuzz_big and not fuzz_batches'
 [ "${3:-light}" = heavy ] && SEL='fuzz_big or fuzz_batches'
-PK_FUZZ_SEEDS=${1:-300} PK_FUZZ_BASE=${2:-1000} python -m pytest tests/test_gpu_parity.py -m gpu -q -k "$SEL" \
+PK_FUZZ_SEEDS=${1:-300} PK_FUZZ_BASE=${2:-1000} python -m pytest tests/test_gpu_parity.py tests/test_gpu_f16_range.py -m gpu -q -k "$SEL" \
   -p no:cacheprovider > gpurun_out/soak.log 2>&1
 rc=$?
 tail -15 gpurun_out/soak.log
