@@ -266,6 +266,7 @@ def other_configs(pk, synth, torch, steps):
     pcm = torch.from_numpy(np.concatenate(waves)).cuda()
     bw = pk.BatchScorer(amw, g, B, int(sum(ns)))
     bw.set_waves_device(pcm.data_ptr(), ns, keep_alive=pcm)
+    bw.calibrate()                               # the deployment flow of the fp16 modes
     bw.score(0.1, sync=True)
     bw.enable_timing(True)
     torch.cuda.synchronize()
@@ -280,6 +281,7 @@ def other_configs(pk, synth, torch, steps):
         "frames_per_s": bw.total_frames() / dt, "ms_per_step": dt * 1e3,
         "gemm_tflops_algorithmic": alg, "gemm_tflops_mfma_issued": 3.0 * alg,
         "fp16_mfma_peak": FP16_MFMA_PEAK_TFLOPS, "frac_of_fp16_peak_issued": 3.0 * alg / FP16_MFMA_PEAK_TFLOPS,
+        "operand_exponents": {"w_exp": [int(e) for e in amw.exponents()[0]], "x_exp_calibrated": [int(e) for e in amw.exponents()[1]]},
         "stage_ms_per_step": {k: bw.timing()[k][0] for k in pk.KINDS}}
     ll_x3 = bw.fetch(0).log_prob()
     bw.close()
@@ -287,6 +289,7 @@ def other_configs(pk, synth, torch, steps):
     amp = pk.AcousticModel(layers, prior, L, R, precision="f16")
     bw = pk.BatchScorer(amp, g, B, int(sum(ns)))
     bw.set_waves_device(pcm.data_ptr(), ns, keep_alive=pcm)
+    bw.calibrate()
     bw.score(0.1, sync=True)
     bw.enable_timing(True)
     torch.cuda.synchronize()
@@ -393,6 +396,22 @@ def main():
         prior = np.full_like(prior, 1.0)
     am = pk.AcousticModel(layers, prior, L, R, precision=args.precision).set_softmax(args.softmax)
     import torch.distributed as tdist
+
+    def calibrate_on_root(model, precision):
+        """fp16 modes, as INTEGRATION.md 3b has a deployment do it right behind pk_load: the root places every
+        layer's input operand inside the fp16 window on one utterance (pk_mi355_batch_calibrate).  The exponents
+        live in the weight blob, so the ONE broadcast below carries them -- a rank left at the default exponents would
+        fail the replica check."""
+        if precision == "f32" or rank != 0:
+            return None
+        w0 = synth.utterance(0, args.seconds)
+        tmp = pk.BatchScorer(model, synth.global_cmvn_stats(), 1, len(w0))
+        tmp.set_waves([w0])
+        tmp.calibrate()
+        tmp.close()
+        return [int(e) for e in model.exponents()[1]]
+
+    calibrated = calibrate_on_root(am, args.precision)
     pkdist.broadcast_model(am, dev, src=0)          # the one RCCL collective of the path (no-op at world 1)
 
     # ---- synthetic PCM, resident in HBM before any timed region
@@ -481,6 +500,7 @@ def main():
         other_prec = "f16x3" if args.precision == "f32" else "f32"
         bs.close()
         am2 = pk.AcousticModel(layers, prior, L, R, precision=other_prec).set_softmax(args.softmax)
+        calibrated2 = calibrate_on_root(am2, other_prec)
         pkdist.broadcast_model(am2, dev, src=0)
         bs2 = pk.BatchScorer(am2, synth.global_cmvn_stats(), args.batch, int(sum(ns)))
         bs2.set_waves_device(pcm.data_ptr(), ns, keep_alive=pcm)
@@ -490,6 +510,7 @@ def main():
                  "ms_per_step": dt2 / args.steps * 1e3,
                  "gemm_tflops_algorithmic": (am2.flops_per_frame() * frames_per_step / (g2 * 1e-3) / 1e12) if g2 > 0 else 0.0,
                  "stage_ms_per_step": {k: tm2[k][0] for k in pk.KINDS},
+                 "operand_exponents_calibrated_on_root": calibrated2,
                  "parity": "f32: affine layers bit-identical to committed outputs of the reference's own SGEMM (gemm.cc + gemm_haswell.cc built here); f16x3: split-fp16 operands on the "
                            "fp16 matrix cores, log-likelihoods within 1e-4*max(|ref|,1) (measured ~1e-6), tests/test_gpu_parity.py"}
         bs2.close()
@@ -527,6 +548,7 @@ def main():
                                    "440 -> %d x %d ReLU -> %d softmax, fbank+CMVN+nnet, PCM resident in HBM"
                                    % (args.batch, args.seconds, nh, hidden, pdfs),
                        "acoustic_model": args.model, "softmax": args.softmax, "utterances_per_gpu": args.batch,
+                       "operand_exponents_calibrated_on_root": calibrated,
                        "frames_per_gpu_per_step": int(frames_per_step),
                        "parallelism": "utterance-sharded x%d, weights broadcast once (%s)" % (
                            world, "RCCL" if args.backend == "nccl" else "gloo rehearsal"),
