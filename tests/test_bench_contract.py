@@ -129,3 +129,19 @@ def test_offline_traffic_figure_is_tied_to_the_gemm_sources(tmp_path, monkeypatc
     f.write_text(json.dumps({"gemm_avg_hbm_bytes_per_launch": 2.5e9, "measured_on": {"gemm_source_hash": B.gemm_source_hash()}}))
     value, why = bench.measured_traffic()
     assert value == 2.5e9 and "same GEMM sources" in why
+
+
+def test_roofline_kernel_label_follows_the_precision_and_the_forced_shape(monkeypatch):
+    """roofline.kernel named GemmF16Kernel / 3 MFMA for every fp16 run.  f16x3 runs GemmF16K32Kernel
+    (16x16x32, 3 MFMA per product), plain f16 GemmF16Kernel (32x32x16, 1 MFMA); PK_MI355_F16_SHAPE forces either."""
+    sys.path.insert(0, REPO)
+    import bench
+    monkeypatch.delenv("PK_MI355_F16_SHAPE", raising=False)
+    assert bench.f16_kernel_label("f32") % 10 == "GemmKernel (fp32 MFMA affine layers, 10 launches/step)"
+    x3, plain = bench.f16_kernel_label("f16x3") % 12, bench.f16_kernel_label("f16") % 12
+    assert x3.startswith("GemmF16K32Kernel (v_mfma_f32_16x16x32_f16, 3 MFMA") and "12 launches" in x3
+    assert plain.startswith("GemmF16Kernel (v_mfma_f32_32x32x16_f16, 1 MFMA")
+    monkeypatch.setenv("PK_MI355_F16_SHAPE", "32")
+    assert (bench.f16_kernel_label("f16x3") % 1).startswith("GemmF16Kernel (v_mfma_f32_32x32x16_f16, 3 MFMA")
+    monkeypatch.setenv("PK_MI355_F16_SHAPE", "16")
+    assert (bench.f16_kernel_label("f16") % 1).startswith("GemmF16K32Kernel (v_mfma_f32_16x16x32_f16, 1 MFMA")
