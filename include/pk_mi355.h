@@ -162,7 +162,7 @@ int pk_mi355_am_precision(const pk_mi355_am_t *am);
  * set_input_exponents: count == number of affine layers, each in [-30, 30].
  * calibrate: feats as for pk_decodable_init (CMVN'd features, {ncol = T, nrow = feat_dim}).  Runs the network on
  *      them, reads every operand's largest magnitude back from the device and sets its exponent so that it lands in
- *      [2^10, 2^11) (32 x headroom to the clamp), layer by layer until all are in band.  The exponents live in the
+ *      [2^3, 2^4) (4 096 x headroom to the clamp; higher placements buy no accuracy), layer by layer, front to back.  The exponents live in the
  *      weight blob: pk_mi355_am_broadcast carries the root's calibration to every rank.  Calibrate while nothing
  *      is being scored with the model.  pk_mi355_batch_calibrate (below) does the same from the batch's waves. */
 int pk_mi355_am_get_exponents(pk_mi355_am_t *am, int32_t *w_exp, int32_t *x_exp, int capacity);

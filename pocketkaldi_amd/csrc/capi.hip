@@ -1395,20 +1395,25 @@ int pk_mi355_am_set_input_exponents(pk_mi355_am_t *am, const int32_t *x_exp, int
 namespace {
 // One calibration decision from the range words of one pass (h_range of `e`, stream synchronised).  Operands are
 // settled front to back: the first operand not yet settled gets the CANONICAL exponent for its measured maximum --
-// the one that puts it into [2^10, 2^11): 32 x headroom below the clamp, 2^15 above the subnormal-lo threshold --
-// whatever exponent it started from, so that a calibration depends on the network and the data only (a saturated
+// the one that puts it into [2^3, 2^4): 4 096 x headroom below the clamp, 2^8 above the too-small threshold, and every
+// element within 2^-6 of the maximum with a normal lo half (smaller ones err by <= 2^-25 absolute, 2^-28 of the
+// maximum: below the dropped lo x lo term).  Higher placements buy no accuracy and can cost clock: normal lo halves toggle
+// more bits in a power-limited mode; measured, the placement is free either way (profiles/r04_f16_calibration_target_ab.txt).  The exponent does not depend on
+// where it started from, so a calibration depends on the network and the data only (a saturated
 // operand, true maximum unknown, first comes down by 2^12 and is looked at again).  Later operands were computed
 // from it, so the caller reruns before looking further.  An operand already settled in this calibration is left
-// alone while it stays inside [2^9, 2^12) (the maxima move in the last bits when an earlier exponent changes).
+// alone while it stays inside [2^1, 2^7) (the maxima move in the last bits when an earlier exponent changes).
 // Returns 1 if an exponent changed, 0 if every operand is settled.
 int CalibrateStep(pk_mi355_am *am, const ExecBufs &e, std::vector<char> *settled) {
   const int nlin = (int)am->lin.size();
+  // PK_MI355_CALIB_TARGET_LOG2: measurement switch for the placement (default 3: the maximum lands in [2^3, 2^4))
+  static const int target = [] { const char *t = getenv("PK_MI355_CALIB_TARGET_LOG2"); const int v = t ? atoi(t) : 3; return v >= 0 && v <= 12 ? v : 3; }();
   for (int l = 0; l < nlin; ++l) {
     const float m = RangeMax(e, l);
     int32_t &xe = am->h_exps[nlin + l];
     int want = xe;
     if (m >= kRangeSaturated) want = xe - 12;
-    else if (m > 0.0f && (!(*settled)[l] || m < 512.0f || m >= 4096.0f)) { want = xe + 10 - ilogbf(m); (*settled)[l] = 1; }
+    else if (m > 0.0f && (!(*settled)[l] || m < ldexpf(1.0f, target - 2) || m >= ldexpf(1.0f, target + 4))) { want = xe + target - ilogbf(m); (*settled)[l] = 1; }
     else (*settled)[l] = 1;                        // an all-zero operand carries nothing to place
     want = std::min(kMaxXExp, std::max(-kMaxXExp, want));
     if (want != xe) { xe = want; return 1; }
