@@ -22,7 +22,7 @@ LIB = os.path.join(HERE, "libpk_mi355.so")
 STAMP = os.path.join(HERE, "libpk_mi355.buildhash")
 HIP_SOURCES = ["frontend.hip", "gemm.hip", "gemm_f16.hip", "tail.hip", "capi.hip"]
 HOST_SOURCES = ["pk_tables.cc"]
-HEADERS = ["pk_kernels.h", "pk_tables.h", "pk_logf.h", "pk_expf.h", "pk_dma.h",
+HEADERS = ["pk_kernels.h", "pk_tables.h", "pk_logf.h", "pk_expf.h", "pk_dma.h", "pk_tail_wave.h",
            os.path.join("..", "..", "include", "pk_mi355.h")]
 ARCH = "gfx950"
 HIP_FLAGS = ["--offload-arch=" + ARCH, "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-Wall",

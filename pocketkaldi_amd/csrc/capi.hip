@@ -216,6 +216,7 @@ struct ExecBufs {
   // PublishRange) and their page-locked host mirror, read after the call (EvalRange)
   uint32_t *range = nullptr, *h_range = nullptr;
   int range_words = 0;
+  unsigned *row_done = nullptr;   // fused tail (gemm.hip, TAIL variant): one arrival counter per 128-row tile, zero between launches
 };
 
 int AllocExec(const pk_mi355_am *am, int64_t rows_cap, ExecBufs *e) {
@@ -235,6 +236,11 @@ int AllocExec(const pk_mi355_am *am, int64_t rows_cap, ExecBufs *e) {
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_range), sizeof(uint32_t) * e->range_words, hipHostMallocDefault));
     memset(e->h_range, 0, sizeof(uint32_t) * e->range_words);
   }
+  {
+    const size_t nd = sizeof(unsigned) * (size_t)(rows_cap / kTile + 2);
+    HIP_TRY(hipMalloc(&e->row_done, nd));
+    HIP_TRY(hipMemset(e->row_done, 0, nd));
+  }
   e->act_floats = (int64_t)am->max_dim_pad * rows_cap;
   e->in_floats = RoundUp(am->input_dim, kBK) * rows_cap;
   HIP_TRY(hipMalloc(&e->a, e->act_floats * sizeof(float)));
@@ -253,6 +259,7 @@ void FreeExec(ExecBufs *e) {
   for (int i = 0; i < 2; ++i) hipFree(e->h[i]);
   hipFree(e->xin);
   hipFree(e->range);
+  hipFree(e->row_done);
   if (e->h_range) hipHostFree(e->h_range);
   *e = ExecBufs();
 }
@@ -311,6 +318,15 @@ int EvalRange(const pk_mi355_am *am, const ExecBufs *const *bufs, int nbufs) {
                   "(pk_mi355_am_calibrate)", mode, l, xe, (double)m);
   }
   return 0;
+}
+
+// fp32 mode, stable softmax: the log-likelihood tail takes the wave-per-row arithmetic of pk_tail_wave.h everywhere --
+// INSIDE the last affine layer's launch where that is a big-tile one (gemm.hip, TAIL variant: +2-3 % on the step,
+// profiles/r04_fused_tail32.txt), as TailWaveKernel elsewhere -- so that a model's log-likelihoods do not depend on
+// the size of the launch that made them.  PK_MI355_FUSED_TAIL32=0 brings TailKernel back (A/B runs, the equality test).
+bool WaveTail32() {
+  const char *c = getenv("PK_MI355_FUSED_TAIL32");
+  return !(c && atoi(c) == 0);
 }
 
 // Run the layer stack on `rows` frames (rows_pad = multiple of 128, <= rows_cap).
@@ -378,6 +394,15 @@ int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t
           g.ldo = D.Npad;
           g.tiles_i = rows_pad / kTile; g.tiles_j = D.Npad / kTile;
         }
+        bool fused_tail = false;
+        if (rows_out && want_tail && !fuse_relu && !am->softmax_reference && i + 2 == nl &&
+            am->layers[i + 1].type == PK_NNET_SOFTMAX_LAYER && WaveTail32()) {
+          g.tail_out = tail_out; g.tail_ld = tail_ld;
+          g.tail_log_prior = blob + am->logprior_off; g.tail_scale = scale;
+          g.tail_n = D.N; g.tail_rows = rows; g.row_done = e.row_done;
+          fused_tail = GemmFusesTail(g);
+          if (!fused_tail) g.tail_out = nullptr;
+        }
         {
           Scoped t(timer, PK_MI355_K_GEMM, stream);
           LaunchGemm(g, stream);
@@ -385,6 +410,7 @@ int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t
         cur = dst; cur_ld = g.ldo; cur_rows = rows_out; cur_splice = false; cur_dim = D.N;
         next_buf ^= 1;
         if (fuse_relu) ++i;
+        if (fused_tail) { tail_done = true; ++i; }
         break;
       }
       case PK_NNET_RELU_LAYER: {
@@ -419,8 +445,10 @@ int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t
         const bool final_layer = (i == nl - 1);
         Scoped t(timer, PK_MI355_K_TAIL, stream);
         if (final_layer && want_tail) {
-          LaunchTail(kTailSoftmaxLoglik, am->softmax_reference, cur, cur_ld, rows, cur_dim,
-                     blob + am->logprior_off, scale, tail_out, tail_ld, stream);
+          if (!(WaveTail32() && !am->softmax_reference &&
+                LaunchTailWave(cur, cur_ld, rows, cur_dim, blob + am->logprior_off, scale, tail_out, tail_ld, stream)))
+            LaunchTail(kTailSoftmaxLoglik, am->softmax_reference, cur, cur_ld, rows, cur_dim,
+                       blob + am->logprior_off, scale, tail_out, tail_ld, stream);
           tail_done = true;
         } else {
           float *dst = bufs[next_buf];
@@ -1464,8 +1492,10 @@ struct pk_mi355_batch {
   CmvnTables *d_cmvn_tab = nullptr;
   int max_utts = 0;
   int64_t max_samples = 0, max_frames = 0, max_cols = 0;
-  int64_t chunk = 131072;  // frames per pass through the layer stack (PK_MI355_CHUNK overrides); measured on
-                           // 256 x 10 s: 65536 -> 25.92, 131072 -> 25.79, 262144 -> 25.78 ms per step
+  int64_t chunk = 262144;  // frames per pass through the layer stack (PK_MI355_CHUNK overrides).  Without the fused tail the
+                           // size hardly matters (256 x 10 s: 65536 -> 25.92, 131072 -> 25.79, 262144 -> 25.78 ms per step);
+                           // with it every last-layer launch ends in ~0.25 ms of tail phases on an emptying chip, so fewer,
+                           // larger passes win: 65536 -> 25.45, 131072 -> 25.0, 262144 -> 24.75 (profiles/r04_fused_tail32.txt)
   // PCM
   float *d_wave = nullptr;          // owned float buffer
   int16_t *d_wave_i16 = nullptr;    // owned int16 buffer

@@ -28,12 +28,14 @@
 // 2..4 chunks of 512, with one group of four waves per chunk (KG) inside the workgroup.
 // The k-loop itself is straight-line code: no branches, no vector address arithmetic.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
 
 #include "pk_dma.h"
 #include "pk_kernels.h"
+#include "pk_tail_wave.h"
 
 #pragma clang fp contract(off)
 
@@ -100,8 +102,29 @@ __device__ __forceinline__ void IssuePiece(const GemmArgs &a, const float *__res
 // R = LDS slabs in a group's ring; R - 1 slabs of DMA are in flight.  R = 3 everywhere: the big
 // tiles spend 6 000 cycles on a slab with three workgroups per CU, and a deeper ring (R = 8)
 // bought the small launches nothing either (measured; they are not latency-bound).
-template <int S, bool SPLICE, bool MULTICHUNK, bool BIAS_J, bool RELU, int KG = 1, int R = 3>
+// The log-likelihood tail of the 128 finished rows of a row tile, by the workgroup that completed it (TAIL variant):
+// pk_tail_wave.h, one wave per row, four rows at a time; sc1 loads (the rows were written by other CUs, possibly on
+// other XCDs: from memory, never from a stale line of this CU's L1 or this XCD's L2).
+template <int C, bool PAIR>
+__device__ __forceinline__ void FusedTailTile(const GemmArgs &a, int i0, float *smem, int tid) {
+  const int nrows = a.tail_rows - i0 < kTile ? a.tail_rows - i0 : kTile;       // workgroup-uniform
+  if (nrows <= 0) return;
+  float *s_prior = smem + 64;                                   // [16, 64): pair exchange; [64, ..): the log priors
+  const int n4 = (a.tail_n + 3) >> 2;
+  for (int i = tid; i < 4 * n4; i += kThreads) s_prior[i] = i < a.tail_n ? TailWavePriorEntry(a.tail_log_prior[i], a.tail_scale) : 0.0f;
+  __syncthreads();
+  const int wave = tid >> 6;
+  const int per_wg = PAIR ? 2 : 4;
+  const int slot = PAIR ? wave >> 1 : wave;
+  TailWaveRows<C, true, PAIR, true>(a.out + (int64_t)i0 * a.ldo, a.ldo, slot, per_wg, (nrows + per_wg - 1) / per_wg, nrows, a.tail_n,
+                                    TailWaveLdsPrior{(const twf4 __attribute__((address_space(3))) *)(s_prior)},
+                                    a.tail_scale, a.tail_out + (int64_t)i0 * a.tail_ld, a.tail_ld,
+                                    tid & 63, wave & 1, smem + 16 + 4 * slot);
+}
+
+template <int S, bool SPLICE, bool MULTICHUNK, bool BIAS_J, bool RELU, int KG = 1, int R = 3, bool TAIL = false>
 __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void GemmKernel(GemmArgs a) {
+  static_assert(!TAIL || (S == 2 && BIAS_J && !RELU && !SPLICE && KG == 1), "fused tail: frame-major logits of big tiles");
   using G = Geo<S>;
   constexpr int kBT = G::kBT, kSlab = G::kSlab, kDma = G::kDma;
   constexpr int kRing = R, kAhead = R - 1;
@@ -120,9 +143,12 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
   const int b = blockIdx.x;
   const int wg = (b % 8) * (nblk / 8) + b / 8;
   const int super_i = (tiles_i + 7) / 8;
-  const int s = wg / 64, w = wg % 64;
+  const int walk_j = TAIL ? a.walk_j : 8;              // the tail variant's super-tiles span a whole row of tiles, so
+                                                       // that rows complete all through the launch, not in its last part
+  const int per = 8 * walk_j;
+  const int s = wg / per, w = wg % per;
   const int ti = (s % super_i) * 8 + (w % 8);
-  const int tj = (s / super_i) * 8 + (w / 8);
+  const int tj = (s / super_i) * walk_j + (w / 8);
   if (ti >= tiles_i || tj >= tiles_j) return;
   const int i0 = ti * kBT, j0 = tj * kBT;
 
@@ -373,14 +399,61 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
         v[y] = t;
       }
       float *dst = obase + (int64_t)(S * ((r & 3) + 8 * (r >> 2))) * a.ldo;
-      if (S == 2) *reinterpret_cast<f32x2 *>(dst) = f32x2{v[0], v[S - 1]};
-      else dst[0] = v[0];
+      if (TAIL) {
+        // write-through (agent-coherent) store: the rows are read back by whichever workgroup completes the row
+        // tile, possibly on another XCD, whose L2 this store must not bypass silently
+        const f32x2 vv = f32x2{v[0], v[S - 1]};
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(vv) : "memory");
+      } else if (S == 2) {
+        *reinterpret_cast<f32x2 *>(dst) = f32x2{v[0], v[S - 1]};
+      } else {
+        dst[0] = v[0];
+      }
+    }
+  }
+
+  if (TAIL) {
+    // Count this tile in once its stores have left (sc1 stores + a drained vmcnt + a relaxed device-scope counter:
+    // placement-independent, no cache maintenance).  The workgroup that brings the row tile's count to tiles_j owns
+    // the 128 finished rows.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    unsigned *mail = reinterpret_cast<unsigned *>(smem_all);        // the rings are idle now
+    // (the thread id is rebuilt from the wave number, a scalar, and the lane count: keeping threadIdx.x alive across
+    // the k loop costs the 167-register kernel a spill)
+    const int tid2 = wave_all * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (tid2 == 0) {
+      const unsigned t = __hip_atomic_fetch_add(a.row_done + ti, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == (unsigned)tiles_j - 1u) __hip_atomic_store(a.row_done + ti, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      mail[0] = t;
+    }
+    __syncthreads();
+    const unsigned ticket = mail[0];
+    __syncthreads();
+    if (ticket != (unsigned)tiles_j - 1u || (a.dbg & 16)) return;   // (dbg 16: hand-off only, a measurement switch)
+    const unsigned long long ph_t0 = __builtin_amdgcn_s_memrealtime();
+    const int chunks = TailWaveChunks(a.tail_n);                    // the EXACT instantiations of tail.hip: LaunchTailWave
+    if (chunks == 4) FusedTailTile<4, false>(a, i0, smem_all, tid2);
+    else if (chunks == 8) FusedTailTile<8, false>(a, i0, smem_all, tid2);
+    else if (chunks == 12) FusedTailTile<12, false>(a, i0, smem_all, tid2);
+    else if (chunks == 16) FusedTailTile<16, false>(a, i0, smem_all, tid2);
+    else if (chunks == 24) FusedTailTile<12, true>(a, i0, smem_all, tid2);
+    else FusedTailTile<16, true>(a, i0, smem_all, tid2);
+    if (a.dbg_counters && tid2 == 0) {                               // measurement: phases and their total duration (100 MHz ticks)
+      atomicAdd(a.dbg_counters, __builtin_amdgcn_s_memrealtime() - ph_t0);
+      atomicAdd(a.dbg_counters + 1, 1ull);
     }
   }
 }
 
 template <int S, bool SPLICE, bool MULTICHUNK, int KG = 1, int R = 3>
 void LaunchVariant(const GemmArgs &a, dim3 grid, dim3 block, hipStream_t stream) {
+  if constexpr (S == 2 && !SPLICE && KG == 1) {
+    if (a.tail_out && a.bias_on_j && !a.relu) {
+      hipLaunchKernelGGL((GemmKernel<S, SPLICE, MULTICHUNK, true, false, KG, R, true>), grid, block, 0, stream, a);
+      return;
+    }
+  }
   if (a.bias_on_j) {
     if (a.relu) hipLaunchKernelGGL((GemmKernel<S, SPLICE, MULTICHUNK, true, true, KG, R>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((GemmKernel<S, SPLICE, MULTICHUNK, true, false, KG, R>), grid, block, 0, stream, a);
@@ -391,10 +464,28 @@ void LaunchVariant(const GemmArgs &a, dim3 grid, dim3 block, hipStream_t stream)
 }
 
 template <int S>
-void LaunchGeo(const GemmArgs &a, hipStream_t stream) {
+void LaunchGeo(const GemmArgs &a_in, hipStream_t stream) {
+  GemmArgs a = a_in;
   const int ti = a.tiles_i * (2 / S), tj = a.tiles_j * (2 / S);
-  const int super_i = (ti + 7) / 8, super_j = (tj + 7) / 8;
-  const int nblk = super_i * super_j * 64;
+  const bool tail = S == 2 && a.tail_out != nullptr;
+  a.walk_j = tail ? tj : 8;                            // (the tail variant: one super-tile column = the whole row of tiles)
+  if (tail) {
+    if (const char *de = getenv("PK_DEBUG_TAILFLAGS")) a.dbg = atoi(de);
+    if (getenv("PK_DEBUG_TAILTIME")) {
+      static unsigned long long *ctr = nullptr;
+      static int calls = 0;
+      if (!ctr) { (void)hipMalloc(&ctr, 16); (void)hipMemset(ctr, 0, 16); }
+      a.dbg_counters = ctr;
+      if (++calls % 16 == 0) {
+        (void)hipStreamSynchronize(stream);
+        unsigned long long h[2];
+        (void)hipMemcpy(h, ctr, 16, hipMemcpyDeviceToHost);
+        fprintf(stderr, "fused tail phases so far: %llu, average %.1f us\n", h[1], h[1] ? h[0] * 0.01 / h[1] : 0.0);
+      }
+    }
+  }
+  const int super_i = (ti + 7) / 8, super_j = (tj + a.walk_j - 1) / a.walk_j;
+  const int nblk = (super_i * super_j * 8 * a.walk_j + 63) / 64 * 64;
   const bool multi = a.K > kChunkK;
   dim3 grid(nblk), block(kThreads);
   // a launch that leaves most SIMDs with one wave: one k-group per 512-chunk (KG x the waves)
@@ -415,6 +506,13 @@ void LaunchGeo(const GemmArgs &a, hipStream_t stream) {
 }
 
 }  // namespace
+
+bool GemmFusesTail(const GemmArgs &a) {
+  const char *mt = getenv("PK_MI355_FUSED_TAIL_MIN_TILES");          // tests lower it to reach the small shapes
+  const int min_tiles = mt && atoi(mt) > 384 ? atoi(mt) : 384;       // (below 384 tiles the small-tile kernel runs: no tail variant)
+  return a.tiles_i * a.tiles_j >= min_tiles && a.bias_on_j && !a.relu && a.splice_dim == 0 && a.tail_n > 0 &&
+         TailWaveExact(a.tail_n);      // (the fused form exists for rows of exactly 4 / 8 / 12 / 16 / 24 / 32 chunks of 256 columns)
+}
 
 void LaunchGemm(const GemmArgs &a, hipStream_t stream) {
   // fewer 128 x 128 tiles than ~1.5 per CU: quarter the tile, quadruple the workgroups

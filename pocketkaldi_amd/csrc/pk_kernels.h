@@ -74,8 +74,23 @@ struct GemmArgs {
   float *out;          // out[i * ldo + j]
   int64_t ldo;
   int tiles_i, tiles_j;
+  // Fused log-likelihood tail (tail_out != nullptr; frame-major output of the last affine layer, big tiles only --
+  // GemmFusesTail()): the workgroup that completes a 128-row tile of logits turns those rows into log-likelihoods
+  // (pk_tail_wave.h), so the logits are never read back by a second launch.
+  float *tail_out = nullptr;       // [rows][tail_ld]
+  int64_t tail_ld = 0;
+  const float *tail_log_prior = nullptr;
+  float tail_scale = 0.0f;
+  int tail_n = 0;                  // valid columns (num_pdfs)
+  int tail_rows = 0;               // valid rows of this launch
+  unsigned *row_done = nullptr;    // one arrival counter per 128-row tile, zero between launches
+  int walk_j = 8;                  // columns of a super-tile of the tile walk (8; the tail variant covers a whole row of tiles)
+  int dbg = 0;                     // measurement switches (PK_DEBUG_TAILFLAGS: 16 = hand-off only)
+  unsigned long long *dbg_counters = nullptr;
 };
 void LaunchGemm(const GemmArgs &a, hipStream_t stream);
+// true if LaunchGemm(a) would run the kernel variant that can carry the fused tail
+bool GemmFusesTail(const GemmArgs &a);
 
 // ---------------------------------------------------------------- affine GEMM, f16x3 mode
 
@@ -154,6 +169,11 @@ enum TailMode {
 // sum, division, libm logf) instead of the overflow-safe log-softmax.
 void LaunchTail(int mode, bool reference_exact, const float *in, int64_t ld_in, int rows, int n,
                 const float *log_prior, float scale, float *out, int64_t ld_out, hipStream_t stream);
+
+// The softmax-log-likelihood tail with one wave per row (pk_tail_wave.h: the arithmetic of the fused last-layer
+// launches).  false: the row is too wide for it (more than 8 192 columns); the caller uses LaunchTail.
+bool LaunchTailWave(const float *in, int64_t ld_in, int rows, int n, const float *log_prior, float scale, float *out,
+                    int64_t ld_out, hipStream_t stream);
 
 // Device-side pk_decodable_loglikelihood (decodable.cc:24-31) for n (frame, trans_id) pairs.
 void LaunchGather(const float *ll, int64_t ld, const int32_t *tid2pdf, int num_tids,

@@ -9,6 +9,7 @@
 #include "pk_expf.h"
 #include "pk_kernels.h"
 #include "pk_logf.h"
+#include "pk_tail_wave.h"
 
 #pragma clang fp contract(off)
 
@@ -544,6 +545,33 @@ __global__ __launch_bounds__(64 * kRegWaves) void TailExactRegKernel(
   }
 }
 
+// The wave-per-row tail as a launch of its own (pk_tail_wave.h; the arithmetic of the fused last-layer launches of
+// gemm.hip, so a model's log-likelihoods do not depend on which form ran).  Four waves per workgroup; the log priors
+// sit in LDS.
+template <int C, bool PAIR, bool EXACT, bool LDS_PRIOR>
+__global__ __launch_bounds__(256) void TailWaveKernel(const float *__restrict__ in, int64_t ld_in, int rows, int n,
+                                                      const float *__restrict__ log_prior, float scale,
+                                                      float *__restrict__ out, int64_t ld_out) {
+  extern __shared__ __attribute__((aligned(16))) float s_prior[];     // 16 floats of pair exchange, then (LDS_PRIOR) the table
+  const int wave = threadIdx.x >> 6;
+  const int per_wg = PAIR ? 2 : 4;                                    // rows a workgroup works on at a time
+  const int slot = PAIR ? wave >> 1 : wave;
+  const int step = gridDim.x * per_wg;
+  const int iters = (rows + step - 1) / step;                          // the same for every wave of every workgroup
+  if (LDS_PRIOR) {
+    const int n4 = (n + 3) >> 2;
+    for (int i = threadIdx.x; i < 4 * n4; i += blockDim.x) s_prior[16 + i] = i < n ? TailWavePriorEntry(log_prior[i], scale) : 0.0f;
+    __syncthreads();
+    TailWaveRows<C, false, PAIR, EXACT>(in, ld_in, blockIdx.x * per_wg + slot, step, iters, rows, n,
+                                        TailWaveLdsPrior{(const twf4 __attribute__((address_space(3))) *)(s_prior + 16)},
+                                        scale, out, ld_out, threadIdx.x & 63, wave & 1, s_prior + 4 * slot);
+  } else {
+    TailWaveRows<C, false, PAIR, EXACT>(in, ld_in, blockIdx.x * per_wg + slot, step, iters, rows, n,
+                                        TailWaveGlobalPrior{log_prior, scale}, scale, out, ld_out, threadIdx.x & 63, wave & 1,
+                                        s_prior + 4 * slot);
+  }
+}
+
 template <int MODE>
 static void LaunchTailMode(const float *in, int64_t ld_in, int rows, int n, const float *log_prior,
                            float scale, float *out, int64_t ld_out, hipStream_t stream) {
@@ -558,6 +586,38 @@ static void LaunchTailMode(const float *in, int64_t ld_in, int rows, int n, cons
     hipLaunchKernelGGL((TailKernel<MODE, kTailCacheMax>), grid, block, 0, stream, in, ld_in, rows, n, log_prior, scale, out, ld_out);
   else
     hipLaunchKernelGGL((TailWideKernel<MODE>), grid, block, 0, stream, in, ld_in, rows, n, log_prior, scale, out, ld_out);
+}
+
+bool LaunchTailWave(const float *in, int64_t ld_in, int rows, int n, const float *log_prior, float scale, float *out,
+                    int64_t ld_out, hipStream_t stream) {
+  const int n4 = (n + 3) / 4;
+  if (n4 > 64 * kTailWaveMaxChunks) return false;
+  if (rows <= 0 || n <= 0) return true;
+  const bool pair = TailWavePair(n);
+  const int per_wg = pair ? 2 : 4;
+  const int wgs = (rows + per_wg - 1) / per_wg < 8192 ? (rows + per_wg - 1) / per_wg : 8192;
+  dim3 grid(wgs), block(256);
+  // few rows per workgroup (a single utterance): the log priors straight from global memory, no table copy
+  const bool lds_prior = rows > 8 * wgs * per_wg;
+  const size_t lds = sizeof(float) * (16 + (lds_prior ? 4 * (size_t)n4 : 0));
+#define PK_TW(CC, P, X) do { if (lds_prior) hipLaunchKernelGGL((TailWaveKernel<CC, P, X, true>), grid, block, lds, stream, in, ld_in, rows, n, log_prior, scale, out, ld_out); \
+                             else hipLaunchKernelGGL((TailWaveKernel<CC, P, X, false>), grid, block, lds, stream, in, ld_in, rows, n, log_prior, scale, out, ld_out); } while (0)
+  const int chunks = TailWaveChunks(n);
+  if (TailWaveExact(n)) {
+    if (chunks == 4) PK_TW(4, false, true);
+    else if (chunks == 8) PK_TW(8, false, true);
+    else if (chunks == 12) PK_TW(12, false, true);
+    else if (chunks == 16) PK_TW(16, false, true);
+    else if (chunks == 24) PK_TW(12, true, true);
+    else PK_TW(16, true, true);
+  } else if (chunks <= 4) PK_TW(4, false, false);
+  else if (chunks <= 8) PK_TW(8, false, false);
+  else if (chunks <= 12) PK_TW(12, false, false);
+  else if (chunks <= 16) PK_TW(16, false, false);
+  else if (chunks <= 24) PK_TW(12, true, false);
+  else PK_TW(16, true, false);
+#undef PK_TW
+  return true;
 }
 
 void LaunchTail(int mode, bool reference_exact, const float *in, int64_t ld_in, int rows, int n,

@@ -1175,3 +1175,42 @@ def test_fuzz_batches_wide_model_both_precisions(seed, monkeypatch):
             else:
                 assert_loglik_close(got, ll)
 
+
+
+@pytest.mark.parametrize("N", [700, 1000, 1501, 3000, 4090, 5000, 6100, 8000])
+def test_fp32_fused_tail_equals_the_stand_alone_wave_tail(N, monkeypatch):
+    """PK_MI355_FUSED_TAIL32=1 (round-4 experiment switch): in fp32 mode the last affine layer's big-tile launch
+    finishes the log-softmax tail itself (gemm.hip, TAIL variant: the workgroup that completes a 128-row tile of
+    logits turns its rows into log-likelihoods), everything else takes TailWaveKernel; both run pk_tail_wave.h, so
+    the two must agree bit for bit at every register-cache width, over several chunks and a ragged last tile; the
+    fused run launches no tail kernel; and the wave arithmetic (hardware exp2, DPP trees) sits inside the contract
+    against the oracle and within 1e-5 of the shipped TailKernel."""
+    rng = np.random.default_rng(N)
+    layers, prior = _random_net(rng, [440, 264, N])
+    g = synth.global_cmvn_stats()
+    lens = [int(rng.integers(8000, 64000)) for _ in range(40)]
+    waves = [synth.utterance(7300 + i, seconds=4.0)[:n].astype(np.int16) for i, n in enumerate(lens)]
+    monkeypatch.setenv("PK_MI355_CHUNK", "16384")
+    got = {}
+    for name, env in (("kernel", {"PK_MI355_FUSED_TAIL32": "0"}),
+                      ("wave", {"PK_MI355_FUSED_TAIL32": "1", "PK_MI355_FUSED_TAIL_MIN_TILES": "100000000"}),
+                      ("fused", {"PK_MI355_FUSED_TAIL32": "1", "PK_MI355_FUSED_TAIL_MIN_TILES": "384"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        am = pk.AcousticModel(layers, prior, 5, 5)
+        bs = pk.BatchScorer(am, g, len(waves), sum(lens))
+        bs.set_waves_i16(waves)
+        bs.enable_timing(True)
+        for _ in range(2):                      # twice: the arrival counters must be back at zero
+            bs.score(0.1)
+        exact = (N + 255) // 256 in (4, 8, 12, 16, 24, 32)       # the row widths that have a fused form (pk_tail_wave.h)
+        assert (bs.timing()["tail"][1] == 0) == (name == "fused" and exact), "only the fused run launches no tail kernel"
+        got[name] = [bs.fetch(u).log_prob().copy() for u in range(len(waves))]
+    for a, b in zip(got["wave"], got["fused"]):
+        assert bits_equal(a, b)
+    for a, b in zip(got["kernel"], got["fused"]):
+        assert np.max(np.abs(a - b) / np.maximum(np.abs(a), 1.0)) < 1e-5
+    nn, fb = O.Nnet(layers), O.Fbank()
+    for u in (0, 17, 39):
+        ref = nn.am_compute(O.cmvn(g, fb.compute(waves[u].astype(np.float32))), prior, 5, 5, 0.1)
+        assert_loglik_close(got["fused"][u], ref)
