@@ -563,6 +563,9 @@ def main():
                          "frac": achieved / peak,
                          "flop_per_frame": am.flops_per_frame(),
                          "kernel_ms_per_step": gemm_ms,
+                         "note": ("fp32 default: the last affine layer's launch also turns its logits into log-likelihoods "
+                                  "(fused tail, DESIGN.md 3.1), so kernel_ms_per_step and `achieved` include the tail's work; "
+                                  "PK_MI355_FUSED_TAIL32=0 separates them again") if args.precision == "f32" and args.softmax == "stable" else None,
                          "algorithmic_bytes_per_launch": None, "traffic": None, "traffic_source": None},
             "stage_ms_per_step": {k: tm[k][0] for k in pk.KINDS},
         }

@@ -170,8 +170,8 @@ int pk_mi355_am_set_input_exponents(pk_mi355_am_t *am, const int32_t *x_exp, int
 int pk_mi355_am_calibrate(pk_mi355_am_t *am, const pk_matrix_t *feats);
 
 /* Arithmetic of the softmax / log-likelihood tail (any time; default STABLE).
- *   STABLE    : log-softmax with the row maximum subtracted -- finite for any logits, within
- *               1e-6 of the reference wherever the reference does not overflow.
+ *   STABLE    : log-softmax with the row maximum subtracted -- finite for any logits, ~1e-6
+ *               (measured 1.2e-6) from the reference wherever the reference does not overflow.
  *   REFERENCE : the reference's operations one by one (nnet.cc:38-47 -> vector.cc:265-277,
  *               am.cc:106-112): libm expf, float sum in column order, division, floor,
  *               libm logf, prior, scale.  With F32 precision the log-likelihoods are then the
