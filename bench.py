@@ -586,6 +586,9 @@ def main():
         # SURVEY 8(d) prices the front-end against HBM by contract; what limits it in practice (PMC):
         out["stage_roofline"]["fbank"]["limited_by"] = "LDS pipe (profiles/r02_fbank_lds.txt, DESIGN.md 3.3)"
         out["stage_roofline"]["cmvn"]["limited_by"] = "the serial window-sum recurrence, one rounding per frame (DESIGN.md 3.4)"
+        if tm["tail"][1] == 0:
+            out["stage_roofline"]["tail"]["limited_by"] = ("no launch of its own: fused into the last affine layer's launch "
+                                                           "(its time is inside the gemm stage, DESIGN.md 3.1 / 3.5)")
         if args.model == "S" and args.batch == 256 and gemm_launches and args.precision == "f32":
             traffic, source = measured_traffic()
             out["roofline"]["traffic"] = traffic
