@@ -1,13 +1,13 @@
-// pk_tail_wave.h -- the log-likelihood tail with one WAVE per row (internal; round-4 experiment switch
-// PK_MI355_FUSED_TAIL32: the fp32 last-layer launch finishing its own rows).
+// pk_tail_wave.h -- the log-likelihood tail of the fp32 mode, one WAVE per row (internal).
 //
 // SoftmaxLayer (nnet.cc:38-47) + the floor / log / prior step of AcousticModel::Compute (am.cc:106-112) + the
 // acoustic scale (decodable.cc:15), overflow-safe:   out = scale * (max(x - lse, log 1e-20) - log prior),
 // lse = m + log sum exp(x - m).  Lane l of the wave owns the 16-byte chunks q = l + 64 c (c < C) of the row, keeps
-// them in registers and reduces with wave shuffles -- no workgroup barrier, no LDS exchange for rows of up to 4 096
-// columns; wider rows are shared by two waves.  exp is the hardware's v_exp_f32 on (x - m) * log2(e) (1 ulp; two instructions,
-// which keeps a row's code to a few hundred of them -- a tail phase inlined with the libm expf ran at instruction-
-// fetch speed: profiles/r04_f16_fused_tail.txt).
+// them in registers and reduces on the vector ALU (DPP) -- no workgroup barrier, no LDS exchange for rows of up to
+// 4 096 columns; wider rows are shared by two waves.  exp is the hardware's v_exp_f32 on fma(x, log2 e, -m log2 e)
+// (1 ulp; two instructions, which keeps a row's code to a few hundred of them -- a tail phase inlined with the libm
+// expf, per-chunk branches and spilled masks ran at 20 cycles per instruction: profiles/r04_f16_fused_tail.txt).
+// Measured against the oracle: 1.2e-6 on log-likelihoods (TailKernel: 0.95e-6); the contract is 1e-4.
 //
 // Two users, ONE arithmetic, so that a model's results do not depend on which of them ran:
 //   * the last affine layer's big-tile launches (gemm.hip, TAIL variant): the workgroup that completes a 128-row
