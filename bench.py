@@ -597,8 +597,16 @@ def main():
             # (layer 1 reads the 40-dim features, the splice is a view)
             lay = [(40, 440, 1024)] + [(1024, 1024, 1024)] * 3 + [(1024, 1024, 3000)]
             rows = frames_per_step + 10 * args.batch
-            out["roofline"]["algorithmic_bytes_per_launch"] = (
-                sum(4.0 * (rows * kin + k * n + rows * n) for kin, k, n in lay) / gemm_launches)
+            alg = sum(4.0 * (rows * kin + k * n + rows * n) for kin, k, n in lay)
+            if tm["tail"][1] == 0:
+                # fused tail: the last layer's launch also writes the log-likelihoods (12 000 B/frame when
+                # fused).  Its logits still make a round trip through memory inside the launch (sc1 stores, read back by the
+                # workgroup that completes the row tile): that round trip is in `traffic`, not in the algorithmic bytes.
+                alg += 4.0 * rows * 3000
+                out["roofline"]["traffic_note"] = ("the last layer's launch moves its logits through memory once more "
+                                                   "(written sc1, read back by the row tile's owner) and writes the log-likelihoods: "
+                                                   "~9.6 GB of the step's traffic is the fused tail, not operand re-reads")
+            out["roofline"]["algorithmic_bytes_per_launch"] = alg / gemm_launches
         if world == 1 and not args.no_host_endpoints and args.precision == "f32":
             bs.close()
             out["endpoints"] = {"device_complete": {"value": value, "unit": "frames/s",
