@@ -440,15 +440,22 @@ def main():
     # into a second, zero-initialised model on every rank, and that model's scores compared across ranks and with
     # the root's real model.  Before the timed region; no new process.
     c_abi_broadcast = "not run (no process group)"
+    binding = comm = None
     if tdist.is_initialized():
         if args.backend != "nccl":
             c_abi_broadcast = "skipped: gloo rehearsal (two RCCL ranks cannot share one device; the C entry runs over a real communicator at nranks = 1 in tests/)"
         elif os.environ.get("PK_BENCH_SKIP_C_ABI", "") == "1":
             c_abi_broadcast = "skipped: PK_BENCH_SKIP_C_ABI=1"
         else:
+            # A communicator that cannot be made (no librccl symbol, a refused bootstrap) is the environment's
+            # failure, not the path's: every rank learns of it through the process group, the line says so, and the
+            # measurement goes on.  A failed broadcast or a score mismatch is the product's and stops the run.
+            binding, comm, why = pkdist.try_make_rccl_comm(rank, world, cdev)
+            if not comm:
+                c_abi_broadcast = "unavailable: no second communicator (%s)" % why
+        if comm:
             zl = [(l[0], np.zeros_like(l[1]), np.zeros_like(l[2])) if l[0] == "linear" else l for l in layers]
             am_z = pk.AcousticModel(zl, np.full_like(prior, 1.0), L, R, precision=args.precision).set_softmax(args.softmax)
-            binding, comm = pkdist.make_rccl_comm(rank, world, cdev)
             try:
                 am_z.broadcast(comm, root=0, src=am)          # on the root the bytes sent are `am`'s; everyone receives into am_z
             finally:

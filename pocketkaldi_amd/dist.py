@@ -193,6 +193,39 @@ def make_rccl_comm(rank, world, device="cpu", binding=None):
     return b, b.comm_init_rank(world, uid, rank)
 
 
+def try_make_rccl_comm(rank, world, device="cpu", binding_factory=RcclBinding):
+    """make_rccl_comm for a caller that must go on without it (bench.py): (binding, comm, "") when EVERY rank joined,
+    else (None, None, reason) on every rank.  Each step that can fail on one rank alone is followed by an agreement
+    over the process group, so no rank is left waiting in a collective the others never enter."""
+    binding, why = None, ""
+    try:
+        binding = binding_factory()
+        os.environ.setdefault("PK_MI355_RCCL_LIB", binding.path)
+    except Exception as e:      # noqa: BLE001 -- the reason travels to the caller
+        why = "%s: %s" % (type(e).__name__, e)
+    if not all_ranks_agree(0.0 if binding else 1.0 + rank, device) or binding is None:
+        return None, None, why or "another rank could not bind RCCL"
+    uid = None
+    if rank == 0:
+        try:
+            uid = binding.unique_id()
+        except Exception as e:      # noqa: BLE001
+            why = "%s: %s" % (type(e).__name__, e)
+    uid = share_bytes(uid, NCCL_UNIQUE_ID_BYTES, 0, device)       # all zero when the root could not draw one
+    if not any(uid):
+        return None, None, why or "the root could not draw an ncclUniqueId"
+    comm = None
+    try:
+        comm = binding.comm_init_rank(world, uid, rank)
+    except Exception as e:      # noqa: BLE001
+        why = "%s: %s" % (type(e).__name__, e)
+    if not all_ranks_agree(0.0 if comm else 1.0 + rank, device) or not comm:
+        if comm:
+            binding.comm_destroy(comm)
+        return None, None, why or "another rank could not join the communicator"
+    return binding, comm, ""
+
+
 def min_max_over_ranks(value, device="cpu"):
     lo = torch.tensor([float(value)], dtype=torch.float64, device=device)
     hi = lo.clone()

@@ -51,6 +51,26 @@ def _worker(rank, world, port, out_dir):
     binding, comm = pkdist.make_rccl_comm(rank, world, "cpu", pkdist.RcclBinding(fake))
     assert comm == 0x5000 + 16 * world + rank
     binding.comm_destroy(comm)
+    # the form bench.py uses, which must leave no rank waiting when one of them cannot join: all succeed ...
+    b2, c2, why = pkdist.try_make_rccl_comm(rank, world, "cpu", lambda: pkdist.RcclBinding(fake))
+    assert c2 == 0x5000 + 16 * world + rank and why == ""
+    b2.comm_destroy(c2)
+    # ... rank 1 has no library to bind: EVERY rank comes back empty-handed, with a reason ...
+
+    def broken():
+        if rank == 1:
+            raise RuntimeError("no RCCL on this rank")
+        return pkdist.RcclBinding(fake)
+    b3, c3, why = pkdist.try_make_rccl_comm(rank, world, "cpu", broken)
+    assert b3 is None and c3 is None and why
+    assert ("no RCCL on this rank" in why) == (rank == 1)
+    # ... rank 1 is refused by ncclCommInitRank (a rank outside the communicator): the joined rank lets go again
+    class Misnumbered(pkdist.RcclBinding):
+        def comm_init_rank(self, nranks, uid_bytes, r):
+            return super().comm_init_rank(nranks, uid_bytes, r + 7 * (r == 1))
+    b4, c4, why = pkdist.try_make_rccl_comm(rank, world, "cpu", lambda: Misnumbered(fake))
+    assert b4 is None and c4 is None and why
+    assert ("invalid argument" in why) == (rank == 1)
     pkdist.barrier()
     open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     pkdist.shutdown()
