@@ -1214,3 +1214,16 @@ def test_fp32_fused_tail_equals_the_stand_alone_wave_tail(N, monkeypatch):
     for u in (0, 17, 39):
         ref = nn.am_compute(O.cmvn(g, fb.compute(waves[u].astype(np.float32))), prior, 5, 5, 0.1)
         assert_loglik_close(got["fused"][u], ref)
+
+
+def test_fused_tail_hand_off_repeats_bit_for_bit_at_the_benchmark_size():
+    """The fused tail's owner reads logits other workgroups stored behind other XCDs' L2s (sc1 stores, an arrival
+    counter, sc1 loads): a visibility bug there would be rare and would only show at sizes the fuzz tests do not
+    reach.  tools/fused_tail_stress.py scores the full 256 x 10 s batch with the tail as its own launch, then N times
+    fused, and compares every byte of [frames][pdfs] each time (soak: 2 000 passes of S, 300 of W; here 40 and 6)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fused_tail_stress", os.path.join(os.path.dirname(G), "..", "tools", "fused_tail_stress.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run("S", 256, 10.0, 40) == 0
+    assert mod.run("W", 256, 10.0, 6) == 0
