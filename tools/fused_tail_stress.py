@@ -65,6 +65,8 @@ def run(model, batch, seconds, passes):
 if __name__ == "__main__":
     ps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     pw = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-    bad = run("S", 256, 10.0, ps)
-    bad += run("W", 256, 10.0, pw)
+    batch = int(os.environ.get("PK_STRESS_BATCH", "256"))          # (ragged shapes: PK_STRESS_BATCH=251 PK_STRESS_SECONDS=9.73,
+    seconds = float(os.environ.get("PK_STRESS_SECONDS", "10"))     #  several launches per pass: PK_MI355_CHUNK=65536)
+    bad = run("S", batch, seconds, ps)
+    bad += run("W", batch, seconds, pw)
     sys.exit(1 if bad else 0)
