@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- acoustic frames/s (fbank -> CMVN -> nnet log-likelihoods) on N MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W           (N > 1: starts the line below itself, as a child)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the whole hot path over one batch of synthetic utterances
@@ -80,7 +80,7 @@ def cpu_baseline(model_name, seconds, budget_s):
         dt += time.perf_counter() - t0
         frames += feats.shape[0]
         num_utts += 1
-    out = {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+    out = {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port", **cpu_identity(),
            "sample": "%d utterances x %.0f s (%d frames), model %s, whole path, %.1f s of CPU (time-capped at %.0f s)"
                      % (num_utts, seconds, frames, model_name, dt, budget_s)}
     # The reference's own SGEMM (gemm.cc + gemm_haswell.cc, built into oracle/_ref/ where the
@@ -147,7 +147,7 @@ def cpu_baseline_all_cores(model_name, seconds, budget_s):
     for t in th:
         t.join()
     dt = time.perf_counter() - t0
-    return {"value": sum(frames) / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": sum(frames) / dt, "unit": "frames/s", "cores": cores, "kind": "port", **cpu_identity(),
             "sample": "%d threads, %.0f s utterances (%d frames), model %s, whole path, %.1f s wall (time-capped at %.0f s)"
                       % (cores, seconds, sum(frames), model_name, dt, budget_s)}
 
@@ -341,6 +341,60 @@ def f16_kernel_label(precision):
     return name + ", " + terms + ", %d launches/step)"
 
 
+def cpu_identity():
+    """CPU model and logical core count of the box the baseline was timed on (every table
+    states core count and CPU model)."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"cpu_model": model or "unknown", "nproc": os.cpu_count() or 0,
+            "affinity_cores": len(os.sched_getaffinity(0))}
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launcher_command(gpus, argv, port):
+    """The driver's own N > 1 command shape, built from this process's arguments."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(gpus, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the ranks as a CHILD
+    torch.distributed.run (one process per GPU) and relay rank 0's single JSON line and the child's exit
+    code.  This process has made no GPU call (torch is not even imported yet): on this pool a process
+    that initialised the GPU must never exec another, and a parent holding the device would take a
+    slot of the card away from the ranks."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = launcher_command(gpus, argv, free_port())
+    print("bench.py: no launcher around --gpus %d, starting: %s" % (gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=REPO)
+    for line in child.stdout:                # rank 0 prints the one contract line; anything else goes to stderr
+        if line.lstrip().startswith("{"):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    return child.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -366,7 +420,13 @@ def main():
                     help="skip the from_pinned_host / host_complete end-points (N = 1 only)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the supplementary BASELINE configs[1] / configs[4] lines (N = 1 only)")
+    ap.add_argument("--ragged", action="store_true",
+                    help="utterance lengths U[2 s, 20 s] (seeded) instead of equal lengths; ranks take the shards "
+                         "pkdist.partition_by_frames gives them (longest-first greedy on the frame count)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
     import pocketkaldi_amd as pk
@@ -375,8 +435,6 @@ def main():
 
     rank, local_rank, world = pkdist.env_world()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
@@ -415,11 +473,29 @@ def main():
     pkdist.broadcast_model(am, dev, src=0)          # the one RCCL collective of the path (no-op at world 1)
 
     # ---- synthetic PCM, resident in HBM before any timed region
-    ids = pkdist.utterance_ids(rank, world, args.batch)
-    waves = [synth.utterance(u, args.seconds) for u in ids]
+    sharding = None
+    if args.ragged:
+        # the reference's real workload is a ragged list (main.cc:34-46): batch x world utterances of U[2 s, 20 s],
+        # sharded by frame count (longest-first greedy); every rank computes the same map, nothing is exchanged
+        secs = [synth.ragged_seconds(u) for u in range(args.batch * world)]
+        frames_all = [pkdist.frames_of(round(s * synth.SAMPLE_RATE)) for s in secs]
+        shards = pkdist.partition_by_frames(frames_all, world)
+        ids = shards[rank]
+        waves = [synth.utterance(u, secs[u]) for u in ids]
+        loads = [sum(frames_all[u] for u in s) for s in shards]
+        sharding = {"policy": "pkdist.partition_by_frames (longest-first greedy on frame counts)",
+                    "utterances": len(secs), "seconds": "U[2, 20] per utterance, seeded by utterance id",
+                    "per_rank_utterances": [len(s) for s in shards], "per_rank_frames": loads,
+                    "imbalance": pkdist.imbalance(frames_all, shards),
+                    "imbalance_u_mod_N": pkdist.imbalance(frames_all, pkdist.partition_round_robin(frames_all, world)),
+                    "imbalance_definition": "max over ranks of the shard's frames / mean - 1"}
+    else:
+        ids = pkdist.utterance_ids(rank, world, args.batch)
+        waves = [synth.utterance(u, args.seconds) for u in ids]
     ns = [len(w) for w in waves]
+    nutts = len(ids)
     pcm = torch.from_numpy(np.concatenate(waves)).to(dev)
-    bs = pk.BatchScorer(am, synth.global_cmvn_stats(), args.batch, int(sum(ns)))
+    bs = pk.BatchScorer(am, synth.global_cmvn_stats(), nutts, int(sum(ns)))
     bs.set_waves_device(pcm.data_ptr(), ns, keep_alive=pcm)
     frames_per_step = bs.total_frames()
 
@@ -469,7 +545,11 @@ def main():
                 c.close()
                 return v
             sz, sa = probe(am_z), probe(am)
-            if not (sz == sa and pkdist.all_ranks_agree(sz, cdev)):
+            # both agreements are collectives EVERY rank enters, whatever its own result (a rank that left before
+            # the all_reduce would leave the others waiting in it): only then do all ranks stop together
+            same_everywhere = pkdist.all_ranks_agree(sz, cdev)
+            all_local_ok = pkdist.all_ranks_agree(0.0 if sz == sa else 1.0 + rank, cdev)
+            if not (same_everywhere and all_local_ok):
                 raise SystemExit("pk_mi355_am_broadcast (C ABI) mismatch: rank %d scores %r, expected %r" % (rank, sz, sa))
             am_z.close()
             c_abi_broadcast = "passed"
@@ -509,7 +589,7 @@ def main():
         am2 = pk.AcousticModel(layers, prior, L, R, precision=other_prec).set_softmax(args.softmax)
         calibrated2 = calibrate_on_root(am2, other_prec)
         pkdist.broadcast_model(am2, dev, src=0)
-        bs2 = pk.BatchScorer(am2, synth.global_cmvn_stats(), args.batch, int(sum(ns)))
+        bs2 = pk.BatchScorer(am2, synth.global_cmvn_stats(), nutts, int(sum(ns)))
         bs2.set_waves_device(pcm.data_ptr(), ns, keep_alive=pcm)
         dt2, tm2 = timed_steps(bs2)
         g2 = tm2["gemm"][0]
@@ -526,7 +606,7 @@ def main():
     ref_softmax = None
     if not args.no_other_precision and args.softmax == "stable" and args.precision == "f32":
         am.set_softmax("reference")
-        bs3 = pk.BatchScorer(am, synth.global_cmvn_stats(), args.batch, int(sum(ns)))
+        bs3 = pk.BatchScorer(am, synth.global_cmvn_stats(), nutts, int(sum(ns)))
         bs3.set_waves_device(pcm.data_ptr(), ns, keep_alive=pcm)
         dt3, tm3 = timed_steps(bs3)
         ref_softmax = {"softmax": "reference", "value": total_frames * args.steps / dt3, "unit": "frames/s",
@@ -551,9 +631,10 @@ def main():
             "dtype": {"f32": "f32", "f16x3": "f16x3 (fp16 hi+lo operands, 3 MFMA per product, f32 accumulate)",
                       "f16": "f16 (plain fp16 operands, f32 accumulate; outside the 1e-4 contract)"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": "%d utterances x %.0f s 16 kHz per GPU (BASELINE configs[2]; x8 = configs[3]), "
-                                   "440 -> %d x %d ReLU -> %d softmax, fbank+CMVN+nnet, PCM resident in HBM"
-                                   % (args.batch, args.seconds, nh, hidden, pdfs),
+            "config": {"workload": ("%d utterances x %s 16 kHz per GPU (BASELINE configs[2]; x8 = configs[3]), "
+                                    "440 -> %d x %d ReLU -> %d softmax, fbank+CMVN+nnet, PCM resident in HBM"
+                                    % (args.batch, "U[2, 20] s (ragged, length-balanced shards)" if args.ragged
+                                       else "%.0f s" % args.seconds, nh, hidden, pdfs)),
                        "acoustic_model": args.model, "softmax": args.softmax, "utterances_per_gpu": args.batch,
                        "operand_exponents_calibrated_on_root": calibrated,
                        "frames_per_gpu_per_step": int(frames_per_step),
@@ -576,6 +657,8 @@ def main():
                          "algorithmic_bytes_per_launch": None, "traffic": None, "traffic_source": None},
             "stage_ms_per_step": {k: tm[k][0] for k in pk.KINDS},
         }
+        if sharding is not None:
+            out["config"]["sharding"] = sharding
         if other is not None:
             out["other_precision"] = other
         if ref_softmax is not None:
@@ -596,14 +679,14 @@ def main():
         if tm["tail"][1] == 0:
             out["stage_roofline"]["tail"]["limited_by"] = ("no launch of its own: fused into the last affine layer's launch "
                                                            "(its time is inside the gemm stage, DESIGN.md 3.1 / 3.5)")
-        if args.model == "S" and args.batch == 256 and gemm_launches and args.precision == "f32":
+        if args.model == "S" and args.batch == 256 and not args.ragged and gemm_launches and args.precision == "f32":
             traffic, source = measured_traffic()
             out["roofline"]["traffic"] = traffic
             out["roofline"]["traffic_source"] = source
             # operands read once + output written once, averaged over the launches of a step
             # (layer 1 reads the 40-dim features, the splice is a view)
             lay = [(40, 440, 1024)] + [(1024, 1024, 1024)] * 3 + [(1024, 1024, 3000)]
-            rows = frames_per_step + 10 * args.batch
+            rows = frames_per_step + 10 * nutts
             alg = sum(4.0 * (rows * kin + k * n + rows * n) for kin, k, n in lay)
             if tm["tail"][1] == 0:
                 # fused tail: the last layer's launch also writes the log-likelihoods (12 000 B/frame when
@@ -620,6 +703,11 @@ def main():
                                                     "start": "float PCM resident in HBM", "end": "log-likelihoods complete in HBM",
                                                     "note": "= value, the headline"}}
             out["endpoints"].update(host_endpoints(pk, synth, am, args.batch, args.seconds))
+            # SURVEY 8(d) defines the metric from PCM in pinned host memory; `value` (the contract's start point: inputs
+            # resident in HBM) stays the headline, the 8(d) start point travels beside it under its own name
+            out["value_from_pinned_host"] = out["endpoints"]["from_pinned_host"]["value"]
+            out["value_from_pinned_host_note"] = ("same workload and unit as `value`, timed from int16 PCM in page-locked host "
+                                                  "memory (upload included, two batches in flight) to log-likelihoods complete in HBM")
         if world == 1 and not args.no_other_configs:
             bs.close()
             out["other_configs"], wide_sample = other_configs(pk, synth, torch, max(2, min(args.steps, 3)))

@@ -46,7 +46,7 @@ def gemm_source_hash():
     and the device compile flags.  tools/profile_gpu.sh records it with every PMC section, so that
     bench.py reports roofline.traffic only from a measurement of THIS kernel (VERDICT round 2, next #6)."""
     h = hashlib.sha256()
-    for s in ["gemm.hip", "pk_dma.h", "pk_kernels.h"]:
+    for s in ["gemm.hip", "pk_dma.h", "pk_kernels.h", "pk_tables.h", "pk_tail_wave.h"]:   # gemm.hip and every header it includes
         with open(os.path.join(CSRC, s), "rb") as f:
             h.update(s.encode() + b"\0" + f.read() + b"\0")
     h.update(" ".join(HIP_FLAGS).encode())

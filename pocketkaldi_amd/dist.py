@@ -40,6 +40,43 @@ def utterance_ids(rank, world, per_rank):
     return [rank + world * i for i in range(per_rank)]
 
 
+def frames_of(num_samples):
+    """Fbank::CalcNumFrames (fbank.cc:35-42): 25 ms windows, 10 ms hop, snip-edges."""
+    n = int(num_samples)
+    return 0 if n < 400 else 1 + (n - 400) // 160
+
+
+def partition_by_frames(frames, world):
+    """Length-balanced sharding for ragged utterance lists (the reference's own
+    workload is a ragged list: main.cc:34-46 scores one WAV after another, each T from fbank.cc:35-42).
+    Longest-first greedy: utterances in order of decreasing frame count, each to the rank with the
+    fewest frames so far (ties: the lower rank; equal lengths keep their input order, so the map is
+    a pure function of `frames` and every rank computes the same one without talking).
+    -> list of `world` lists of utterance indices, each in increasing order."""
+    import heapq
+    order = sorted(range(len(frames)), key=lambda u: (-int(frames[u]), u))
+    heap = [(0, r) for r in range(world)]
+    shards = [[] for _ in range(world)]
+    for u in order:
+        load, r = heapq.heappop(heap)
+        shards[r].append(u)
+        heapq.heappush(heap, (load + int(frames[u]), r))
+    return [sorted(s) for s in shards]
+
+
+def partition_round_robin(frames, world):
+    """u -> rank u mod world over the same list (what utterance_ids does for equal lengths)."""
+    return [list(range(r, len(frames), world)) for r in range(world)]
+
+
+def imbalance(frames, shards):
+    """max over ranks of the shard's frames / mean - 1: the fraction of the slowest rank's time the
+    average rank would sit idle."""
+    loads = [sum(int(frames[u]) for u in s) for s in shards]
+    mean = sum(loads) / float(len(loads))
+    return (max(loads) / mean - 1.0) if mean > 0 else 0.0
+
+
 def broadcast_blob(blob_u8, src=0):
     """The one collective of the path: rank `src`'s weight blob to every rank, in place.
     (With the gloo rehearsal backend a device tensor is staged through the host.)"""

@@ -25,6 +25,13 @@ def utterance(utt_id, seconds=10.0, dtype=np.float32):
     return np.round(np.clip(s, -32767, 32767)).astype(dtype)
 
 
+def ragged_seconds(utt_id, lo=2.0, hi=20.0):
+    """Length of utterance `utt_id` in bench.py's ragged workload: U[lo, hi] seconds, seeded by the id
+    alone (every rank computes the whole list), rounded to a whole sample."""
+    s = np.random.default_rng(0xBA5E0 + int(utt_id)).uniform(lo, hi)
+    return round(s * SAMPLE_RATE) / SAMPLE_RATE
+
+
 def global_cmvn_stats():
     gn = 1.0e6
     g = np.empty(41, dtype=np.float32)

@@ -40,6 +40,12 @@ def test_bench_line_has_the_contract_keys():
     assert "time-capped" in c["sample"] and "time-capped" in d["cpu_baseline_all_cores"]["sample"]
     # value = frames of all steps / wall time
     assert abs(d["value"] - d["config"]["frames_per_gpu_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    # round 5: CPU model and core count beside every CPU number; SURVEY 8(d)'s start
+    # point (pinned host memory) as a named top-level number next to `value`
+    for leg in (c, d["cpu_baseline_all_cores"]):
+        assert isinstance(leg["cpu_model"], str) and leg["cpu_model"] and leg["nproc"] >= 1 and leg["affinity_cores"] >= 1
+    assert d["value_from_pinned_host"] == e["from_pinned_host"]["value"]
+    assert "page-locked" in d["value_from_pinned_host_note"]
 
 
 def _one_json_line(stdout):
@@ -113,6 +119,58 @@ def test_forced_process_group_runs_the_real_rccl_broadcast_inside_bench():
     assert abs(pr["min"] - pr["max"]) < 1e-9 * pr["max"] and pr["max"] >= d["value"] * 0.999
 
 
+def _launch_env():
+    env = dict(os.environ, PYTHONPATH=REPO)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PK_DIST_FORCE"):
+        env.pop(k, None)
+    return env
+
+
+@pytest.mark.gpu
+def test_bare_gpus_2_launches_its_own_ranks_and_prints_one_line():
+    """VERDICT round 4, next #1: `python bench.py --gpus N` with NO launcher around it (the N = 1 command shape
+    with another N) starts torch.distributed.run itself, as a child, and relays rank 0's one line and the exit code.
+    Two ranks share the one GPU here (gloo); ragged utterances exercise the length-balanced sharding."""
+    r = subprocess.run(
+        [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--ragged",
+         "--batch", "6", "--steps", "2", "--warmup", "1", "--no-other-precision"],
+        capture_output=True, text=True, cwd=REPO, env=_launch_env(), timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                       # nothing but the contract line reaches stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["collective"]["replica_check"] == "passed" and d["config"]["collective"]["process_group"] is True
+    sh = d["config"]["sharding"]
+    assert sh["utterances"] == 12 and sum(sh["per_rank_utterances"]) == 12 and len(sh["per_rank_frames"]) == 2
+    assert sh["per_rank_frames"][0] == d["config"]["frames_per_gpu_per_step"]          # rank 0's shard
+    assert 0.0 <= sh["imbalance"] <= sh["imbalance_u_mod_N"] + 1e-12
+    total = sum(sh["per_rank_frames"])
+    assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert "torch.distributed.run" in r.stderr             # the launcher line is on stderr
+
+
+def test_bare_gpus_2_starts_two_ranks_without_touching_the_gpu_in_the_parent():
+    """The same entry on a box WITHOUT a GPU: the parent must get as far as starting the child launcher (it makes no
+    GPU call and does not import torch), both ranks then refuse to run without an MI355X, and the parent relays the
+    launcher's non-zero exit code with nothing on stdout."""
+    sys.path.insert(0, REPO)
+    import bench
+    cmd = bench.launcher_command(8, ["--gpus", "8", "--steps", "3"], 29123)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29123" and cmd[-4:] == ["--gpus", "8", "--steps", "3"]
+    assert os.path.samefile(cmd[-5], os.path.join(REPO, "bench.py"))
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the launch itself is test_bare_gpus_2_launches_its_own_ranks_and_prints_one_line")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                        "--batch", "2", "--seconds", "1", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, cwd=REPO, env=_launch_env(), timeout=600)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "no launcher around --gpus 2" in r.stderr and r.stderr.count("needs an MI355X") >= 2, r.stderr[-3000:]
+
+
 def test_offline_traffic_figure_is_tied_to_the_gemm_sources(tmp_path, monkeypatch):
     """roofline.traffic comes from committed PMC passes; it is reported only when that file says it was
     measured on the GEMM sources the running library is built from (VERDICT round 2, next #6)."""
@@ -129,6 +187,9 @@ def test_offline_traffic_figure_is_tied_to_the_gemm_sources(tmp_path, monkeypatc
     f.write_text(json.dumps({"gemm_avg_hbm_bytes_per_launch": 2.5e9, "measured_on": {"gemm_source_hash": B.gemm_source_hash()}}))
     value, why = bench.measured_traffic()
     assert value == 2.5e9 and "same GEMM sources" in why
+    # the dominant launch runs the tail too: its header is part of what the figure is tied to
+    import inspect
+    assert "pk_tail_wave.h" in inspect.getsource(B.gemm_source_hash)
 
 
 def test_roofline_kernel_label_follows_the_precision_and_the_forced_shape(monkeypatch):
