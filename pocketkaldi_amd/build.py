@@ -20,16 +20,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpk_mi355.so")
 STAMP = os.path.join(HERE, "libpk_mi355.buildhash")
-HIP_SOURCES = ["frontend.hip", "gemm.hip", "gemm_f16.hip", "tail.hip", "capi.hip"]
+HIP_SOURCES = ["frontend.hip", "gemm.hip", "gemm_f16.hip", "tail.hip", "capi_model.hip", "capi_exec.hip", "capi_batch.hip",
+               "capi_io.hip", "capi_collective.hip"]
 HOST_SOURCES = ["pk_tables.cc"]
-HEADERS = ["pk_kernels.h", "pk_tables.h", "pk_logf.h", "pk_expf.h", "pk_dma.h", "pk_tail_wave.h",
+HEADERS = ["pk_kernels.h", "pk_tables.h", "pk_logf.h", "pk_expf.h", "pk_dma.h", "pk_tail_wave.h", "pk_host.h", "libpk_mi355.map",
            os.path.join("..", "..", "include", "pk_mi355.h")]
 ARCH = "gfx950"
 HIP_FLAGS = ["--offload-arch=" + ARCH, "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-Wall",
              "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 HOST_FLAGS = ["-std=c++17", "-O2", "-ffp-contract=off", "-fPIC"]
-# RCCL is bound at run time (dlopen in capi.hip): the library has no link-time dependency on it
-LINK_LIBS = ["-ldl"]
+# RCCL is bound at run time (dlopen in capi_collective.hip): the library has no link-time dependency on it.
+# The version script exports the C entries of include/pk_mi355.h and nothing else.
+LINK_LIBS = ["-ldl", "-Wl,--version-script=" + os.path.join(CSRC, "libpk_mi355.map")]
+LINK_ID = ["-ldl", "-Wl,--version-script=libpk_mi355.map"]      # what the content hash sees: no absolute path (the tree moves)
 
 
 def source_hash():
@@ -37,7 +40,7 @@ def source_hash():
     for s in HIP_SOURCES + HOST_SOURCES + HEADERS:
         with open(os.path.join(CSRC, s), "rb") as f:
             h.update(s.encode() + b"\0" + f.read() + b"\0")
-    h.update(" ".join(HIP_FLAGS + HOST_FLAGS + LINK_LIBS).encode())
+    h.update(" ".join(HIP_FLAGS + HOST_FLAGS + LINK_ID).encode())
     return h.hexdigest()
 
 
@@ -96,7 +99,7 @@ def _build_locked(verbose):
             objs.append(o)
             subprocess.check_call(cmd)
         procs = []
-        for s in HIP_SOURCES:                       # the five translation units are independent
+        for s in HIP_SOURCES:                       # the translation units are independent
             o = os.path.join(CSRC, "%s.%d.o" % (s, pid))
             cmd = [hipcc] + HIP_FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
             if verbose:

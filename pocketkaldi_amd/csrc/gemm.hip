@@ -423,15 +423,17 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
     // the k loop costs the 167-register kernel a spill)
     const int tid2 = wave_all * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     if (tid2 == 0) {
-      const unsigned t = __hip_atomic_fetch_add(a.row_done + ti, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t == (unsigned)tiles_j - 1u) __hip_atomic_store(a.row_done + ti, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      mail[0] = t;
+      // (the host zeroes the counters in front of every launch: capi_exec.hip, RunLayers)
+      mail[0] = __hip_atomic_fetch_add(a.row_done + ti, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     const unsigned ticket = mail[0];
     __syncthreads();
-    if (ticket != (unsigned)tiles_j - 1u || (a.dbg & 16)) return;   // (dbg 16: hand-off only, a measurement switch)
+    if (ticket != (unsigned)tiles_j - 1u) return;
+#ifdef PK_MI355_DIAG
+    if (a.dbg & 16) return;                                         // hand-off only: a measurement switch (results are NOT made)
     const unsigned long long ph_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int chunks = TailWaveChunks(a.tail_n);                    // the EXACT instantiations of tail.hip: LaunchTailWave
     if (chunks == 4) FusedTailTile<4, false>(a, i0, smem_all, tid2);
     else if (chunks == 8) FusedTailTile<8, false>(a, i0, smem_all, tid2);
@@ -439,10 +441,12 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
     else if (chunks == 16) FusedTailTile<16, false>(a, i0, smem_all, tid2);
     else if (chunks == 24) FusedTailTile<12, true>(a, i0, smem_all, tid2);
     else FusedTailTile<16, true>(a, i0, smem_all, tid2);
+#ifdef PK_MI355_DIAG
     if (a.dbg_counters && tid2 == 0) {                               // measurement: phases and their total duration (100 MHz ticks)
       atomicAdd(a.dbg_counters, __builtin_amdgcn_s_memrealtime() - ph_t0);
       atomicAdd(a.dbg_counters + 1, 1ull);
     }
+#endif
   }
 }
 
@@ -468,7 +472,11 @@ void LaunchGeo(const GemmArgs &a_in, hipStream_t stream) {
   GemmArgs a = a_in;
   const int ti = a.tiles_i * (2 / S), tj = a.tiles_j * (2 / S);
   const bool tail = S == 2 && a.tail_out != nullptr;
-  a.walk_j = tail ? tj : 8;                            // (the tail variant: one super-tile column = the whole row of tiles)
+  // the tail variant: one super-tile column = the whole row of tiles, so that rows complete all through the launch
+  // (tail_walk > 0: an A/B switch, super-tile columns of 8 x tail_walk tiles walked row-super-tile first)
+  a.walk_j = tail ? (a.tail_walk > 0 && a.tail_walk < tj ? a.tail_walk : tj) : 8;
+#ifdef PK_MI355_DIAG
+  // measurement hooks of the fused tail (diagnostic builds only: -DPK_MI355_DIAG; never in the product library)
   if (tail) {
     if (const char *de = getenv("PK_DEBUG_TAILFLAGS")) a.dbg = atoi(de);
     if (getenv("PK_DEBUG_TAILTIME")) {
@@ -484,6 +492,7 @@ void LaunchGeo(const GemmArgs &a_in, hipStream_t stream) {
       }
     }
   }
+#endif
   const int super_i = (ti + 7) / 8, super_j = (tj + a.walk_j - 1) / a.walk_j;
   const int nblk = (super_i * super_j * 8 * a.walk_j + 63) / 64 * 64;
   const bool multi = a.K > kChunkK;
@@ -507,10 +516,9 @@ void LaunchGeo(const GemmArgs &a_in, hipStream_t stream) {
 
 }  // namespace
 
-bool GemmFusesTail(const GemmArgs &a) {
-  const char *mt = getenv("PK_MI355_FUSED_TAIL_MIN_TILES");          // tests lower it to reach the small shapes
-  const int min_tiles = mt && atoi(mt) > 384 ? atoi(mt) : 384;       // (below 384 tiles the small-tile kernel runs: no tail variant)
-  return a.tiles_i * a.tiles_j >= min_tiles && a.bias_on_j && !a.relu && a.splice_dim == 0 && a.tail_n > 0 &&
+bool GemmFusesTail(const GemmArgs &a, int min_tiles) {
+  if (min_tiles < 384) min_tiles = 384;                               // (below 384 tiles the small-tile kernel runs: no tail variant)
+  return (int64_t)a.tiles_i * a.tiles_j >= min_tiles && a.bias_on_j && !a.relu && a.splice_dim == 0 && a.tail_n > 0 &&
          TailWaveExact(a.tail_n);      // (the fused form exists for rows of exactly 4 / 8 / 12 / 16 / 24 / 32 chunks of 256 columns)
 }
 

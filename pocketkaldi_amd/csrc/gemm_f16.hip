@@ -98,7 +98,7 @@ __device__ __forceinline__ float Pow2(int e) { return __int_as_float((127 + e) <
 // (unsigned order = float order).  One relaxed read + at most one fire-and-forget atomic per wave; the words of
 // an operand are spread over kRangeSlots addresses so the atomics of a launch do not queue on one L2 line.
 // The host reads them after the call: >= 65504 means the split clamped (saturation), a positive value below
-// 2^-5 means every lo half of the operand was subnormal (capi.hip: EvalRange).
+// 2^-5 means every lo half of the operand was subnormal (capi_exec.hip: EvalRange).
 __device__ __forceinline__ void PublishRange(uint32_t *range, int slot, float wave_max) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) wave_max = fmaxf(wave_max, __shfl_xor(wave_max, m));

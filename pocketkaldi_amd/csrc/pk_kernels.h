@@ -83,14 +83,18 @@ struct GemmArgs {
   float tail_scale = 0.0f;
   int tail_n = 0;                  // valid columns (num_pdfs)
   int tail_rows = 0;               // valid rows of this launch
-  unsigned *row_done = nullptr;    // one arrival counter per 128-row tile, zero between launches
-  int walk_j = 8;                  // columns of a super-tile of the tile walk (8; the tail variant covers a whole row of tiles)
+  unsigned *row_done = nullptr;    // one arrival counter per 128-row tile; the caller zeroes tiles_i of them in front of the launch
+  int tail_walk = 0;               // A/B switch: super-tile columns of the tail variant's walk (0: the whole row of tiles)
+  int walk_j = 8;                  // (set by the launcher) columns of a super-tile of the tile walk
+#ifdef PK_MI355_DIAG
   int dbg = 0;                     // measurement switches (PK_DEBUG_TAILFLAGS: 16 = hand-off only)
   unsigned long long *dbg_counters = nullptr;
+#endif
 };
 void LaunchGemm(const GemmArgs &a, hipStream_t stream);
-// true if LaunchGemm(a) would run the kernel variant that can carry the fused tail
-bool GemmFusesTail(const GemmArgs &a);
+// true if LaunchGemm(a) would run the kernel variant that carries the fused tail; min_tiles: the smallest launch
+// (in 128 x 128 tiles, at least 384) that does
+bool GemmFusesTail(const GemmArgs &a, int min_tiles);
 
 // ---------------------------------------------------------------- affine GEMM, f16x3 mode
 

@@ -154,6 +154,11 @@ __device__ __forceinline__ void TailWaveRows(const float *__restrict__ in, int64
     }
     if (live) {
       const float lse = m + logf(s);
+      // A row with a NaN logit (or +inf, or nothing but -inf) has lse = NaN and must come out NaN, as the reference's
+      // does (am.cc:109 `x < 1e-20` is false for NaN, log follows): v_max_f32(NaN, floor) would return the floor and
+      // turn the row into plausible numbers.  One select per ROW instead of a compare-select per element: the floor
+      // operand itself becomes NaN, and max(NaN, NaN) = NaN.  (lse is finite for every other row: s is in [1, 8192].)
+      const float row_floor = (lse == lse) ? kLogFloor : lse;
       // the row as a buffer of n floats: a store past its end is dropped by the range check
       const __amdgpu_buffer_rsrc_t yrow = __builtin_amdgcn_make_buffer_rsrc(out + (int64_t)row * ld_out, 0, n * 4, 0x00020000);
 #pragma unroll
@@ -163,7 +168,7 @@ __device__ __forceinline__ void TailWaveRows(const float *__restrict__ in, int64
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float t = v[c][e] - lse;                                               // log softmax, stable form
-          t = fmaxf(t, kLogFloor);                                               // floor of am.cc:109 in the log domain
+          t = fmaxf(t, row_floor);                                               // floor of am.cc:109 in the log domain
           o[e] = __builtin_fmaf(t, scale, lp[e]);                                // (t - log prior) * scale (am.cc:111, decodable.cc:15);
                                                                                  // the table holds -log prior * scale
         }

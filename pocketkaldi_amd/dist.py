@@ -225,7 +225,7 @@ def make_rccl_comm(rank, world, device="cpu", binding=None):
     """(binding, ncclComm_t) over all ranks of the job: rank 0 draws the id, one small broadcast shares it,
     every rank joins.  No new process, nothing re-executed."""
     b = binding or RcclBinding()
-    os.environ.setdefault("PK_MI355_RCCL_LIB", b.path)    # libpk_mi355 binds ncclBroadcast in the same copy (capi.hip: BindRccl)
+    os.environ.setdefault("PK_MI355_RCCL_LIB", b.path)    # libpk_mi355 binds ncclBroadcast in the same copy (capi_collective.hip: BindRccl)
     uid = share_bytes(b.unique_id() if rank == 0 else None, NCCL_UNIQUE_ID_BYTES, 0, device)
     return b, b.comm_init_rank(world, uid, rank)
 

@@ -29,6 +29,16 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), name
 
 
+def test_library_exports_nothing_but_the_declared_abi():
+    """Round 5: the link goes through csrc/libpk_mi355.map -- the dynamic symbol table IS the header (launchers, kernel
+    stubs and host helpers of the five host units stay local), so splitting capi.hip changed no exported name."""
+    import subprocess
+    pk.lib()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", pk.lib_path()], text=True)
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == declared_functions()
+
+
 def test_struct_layout_matches_reference_abi():
     # decodable.h:15-18 on LP64: {int ncol; int nrow; float *data;} + pointer = 16 + 8
     assert ctypes.sizeof(pk.pk_matrix_t) == 16

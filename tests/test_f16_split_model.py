@@ -1,7 +1,7 @@
 """CPU model of the f16x3 arithmetic (csrc/gemm_f16.hip: x = hi + lo, D = sum hi hi + hi lo + lo hi in fp32), numpy
 float16 with subnormals, to pin down WHY the round-4 power-of-two prescale is needed and that it is exact:
   * unscaled, the error grows as the weights shrink (the lo halves fall into fp16 subnormals, then vanish);
-  * prescaled so that max |W| is in [2^13, 2^14) -- what pk_mi355_am_finalize does (capi.hip) -- the error is
+  * prescaled so that max |W| is in [2^13, 2^14) -- what pk_mi355_am_finalize does (capi_model.hip) -- the error is
     the same at every scale, and the scaling itself changes no bit of the exact product.
 No GPU, no product code: this is the arithmetic the GPU tests in test_gpu_f16_range.py then hold the kernels to.
 """
@@ -23,7 +23,7 @@ def f16x3_matmul(X, W):
 
 
 def finalize_exponent(W):
-    """capi.hip, pk_mi355_am_finalize: 13 - ilogb(max |W|), clamped to +-60."""
+    """capi_model.hip, pk_mi355_am_finalize: 13 - ilogb(max |W|), clamped to +-60."""
     m = np.abs(W).max()
     return 0 if m == 0 else int(np.clip(13 - int(np.floor(np.log2(m))), -60, 60))
 

@@ -1216,6 +1216,37 @@ def test_fp32_fused_tail_equals_the_stand_alone_wave_tail(N, monkeypatch):
         assert_loglik_close(got["fused"][u], ref)
 
 
+@pytest.mark.parametrize("path", ["kernel", "wave", "fused"])
+def test_stable_tail_keeps_nan_rows_nan(path, monkeypatch):
+    """with the DEFAULT (stable) softmax a row with a NaN logit must come out NaN, as the reference's
+    does (am.cc:109: `x < 1e-20` is false for NaN, so log(NaN) follows) -- v_max_f32(NaN, floor) returned the floor
+    and turned such rows into plausible log-likelihoods with rc 0.  NaN features in a few frames make the rows within
+    the splice context of those frames NaN and no others; all three tails: TailKernel (PK_MI355_FUSED_TAIL32=0), the
+    stand-alone wave tail, and the tail fused into the last layer's launch (4 096-row chunk x 24 column tiles; the
+    404-row remainder takes the wave tail)."""
+    for k, v in {"kernel": {"PK_MI355_FUSED_TAIL32": "0"},
+                 "wave": {"PK_MI355_FUSED_TAIL32": "1", "PK_MI355_FUSED_TAIL_MIN_TILES": "100000000"},
+                 "fused": {"PK_MI355_FUSED_TAIL32": "1", "PK_MI355_FUSED_TAIL_MIN_TILES": "384"}}[path].items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(77)
+    layers, prior = _random_net(rng, [440, 264, 3000])
+    T = 4500
+    feats = rng.standard_normal((T, 40)).astype(np.float32)
+    bad_frames = [7, 2000, 4094, 4400]
+    for t in bad_frames:
+        feats[t, int(rng.integers(0, 40))] = np.nan
+    am = pk.AcousticModel(layers, prior, 5, 5)
+    got = pk.Decodable(am, 0.1, feats).log_prob()
+    ref = O.Nnet(layers).am_compute(feats, prior, 5, 5, 0.1)
+    nan_rows = np.isnan(ref).all(axis=1)
+    want_rows = np.zeros(T, bool)
+    for t in bad_frames:
+        want_rows[max(0, t - 5):t + 6] = True
+    assert np.array_equal(nan_rows, want_rows) and not np.isnan(ref[~nan_rows]).any()      # what the reference does
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), "NaN placement differs from the reference's"
+    assert_loglik_close(got[~nan_rows], ref[~nan_rows])
+
+
 def test_fused_tail_hand_off_repeats_bit_for_bit_at_the_benchmark_size():
     """The fused tail's owner reads logits other workgroups stored behind other XCDs' L2s (sc1 stores, an arrival
     counter, sc1 loads): a visibility bug there would be rare and would only show at sizes the fuzz tests do not

@@ -24,25 +24,34 @@ from pocketkaldi_amd import synth               # noqa: E402
 
 def run(model, batch, seconds, passes):
     layers, prior, L, R = synth.model(model)
-    am = pk.AcousticModel(layers, prior, L, R)
     waves = [synth.utterance(u, seconds) for u in range(batch)]
     ns = [len(w) for w in waves]
     dev = torch.device("cuda:0")
     pcm = torch.from_numpy(np.concatenate(waves)).to(dev)
-    bs = pk.BatchScorer(am, synth.global_cmvn_stats(), batch, int(sum(ns)))
-    bs.set_waves_device(pcm.data_ptr(), ns, keep_alive=pcm)
-    n = am.num_pdfs()
-    first = bs.loglik_device(0)
-    last_rows = bs.num_frames(batch - 1)
-    nbytes = (bs.loglik_device(batch - 1) - first) + last_rows * n * 4
-    view = pkdist.alias_device_bytes(first, nbytes, dev)
+
+    def scorer():
+        am_ = pk.AcousticModel(layers, prior, L, R)       # (the PK_MI355_* switches are read when a model is made)
+        bs_ = pk.BatchScorer(am_, synth.global_cmvn_stats(), batch, int(sum(ns)))
+        bs_.set_waves_device(pcm.data_ptr(), ns, keep_alive=pcm)
+        n_ = am_.num_pdfs()
+        first = bs_.loglik_device(0)
+        nbytes_ = (bs_.loglik_device(batch - 1) - first) + bs_.num_frames(batch - 1) * n_ * 4
+        return am_, bs_, n_, nbytes_, pkdist.alias_device_bytes(first, nbytes_, dev)
 
     os.environ["PK_MI355_FUSED_TAIL_MIN_TILES"] = "2000000000"      # the tail as a launch of its own
-    bs.score(0.1, sync=True)
-    want = view.clone()
-    bs.score(0.1, sync=True)
-    assert torch.equal(view, want), "the stand-alone form is not even reproducible"
+    am0, bs0, n, nbytes, view0 = scorer()
     del os.environ["PK_MI355_FUSED_TAIL_MIN_TILES"]
+    bs0.score(0.1, sync=True)
+    want = view0.clone()
+    bs0.score(0.1, sync=True)
+    assert torch.equal(view0, want), "the stand-alone form is not even reproducible"
+    bs0.enable_timing(True)
+    bs0.score(0.1, sync=True)
+    assert bs0.timing()["tail"][1] > 0, "the comparison run was meant to launch the tail on its own"
+    del view0
+    bs0.close()
+    am0.close()
+    am, bs, n, nbytes, view = scorer()
 
     bad = 0
     t0 = time.perf_counter()
