@@ -308,7 +308,9 @@ int pk_mi355_batch_fetch(pk_mi355_batch_t *b, int utt, pk_decodable_t *out);
  * destroyed; the views of the LAST fetch_all in fact stay readable until the last of them goes.  With sync == 0 the copy is queued on
  * the device's result stream, ordered after this batch's scoring and before anything queued
  * later on the batch's stream; pk_mi355_batch_synchronize completes it, so it overlaps another
- * batch's scoring.                                                                           */
+ * batch's scoring.  F16X3 / F16 with sync == 0: the views exist before the score call's range verdict does; if
+ * pk_mi355_batch_synchronize then returns PK_MI355_E_RANGE the results are withheld -- pk_decodable_loglikelihood
+ * on those views returns NaN from then on (do not read log_prob.data of views whose synchronize failed).      */
 int pk_mi355_batch_fetch_all(pk_mi355_batch_t *b, pk_decodable_t *out, int num_out, int sync);
 /* Intermediate stages, for parity tests: raw fbank / CMVN'd features of utt,
  * copied to host as [T][40].                                                     */

@@ -23,7 +23,7 @@ STAMP = os.path.join(HERE, "libpk_mi355.buildhash")
 HIP_SOURCES = ["frontend.hip", "gemm.hip", "gemm_f16.hip", "tail.hip", "capi_model.hip", "capi_exec.hip", "capi_batch.hip",
                "capi_io.hip", "capi_collective.hip"]
 HOST_SOURCES = ["pk_tables.cc"]
-HEADERS = ["pk_kernels.h", "pk_tables.h", "pk_logf.h", "pk_expf.h", "pk_dma.h", "pk_tail_wave.h", "pk_host.h", "libpk_mi355.map",
+HEADERS = ["pk_kernels.h", "pk_tables.h", "pk_logf.h", "pk_expf.h", "pk_dma.h", "pk_tail_wave.h", "pk_wave.h", "pk_host.h", "libpk_mi355.map",
            os.path.join("..", "..", "include", "pk_mi355.h")]
 ARCH = "gfx950"
 HIP_FLAGS = ["--offload-arch=" + ARCH, "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-Wall",
@@ -49,7 +49,7 @@ def gemm_source_hash():
     and the device compile flags.  tools/profile_gpu.sh records it with every PMC section, so that
     bench.py reports roofline.traffic only from a measurement of THIS kernel (VERDICT round 2, next #6)."""
     h = hashlib.sha256()
-    for s in ["gemm.hip", "pk_dma.h", "pk_kernels.h", "pk_tables.h", "pk_tail_wave.h"]:   # gemm.hip and every header it includes
+    for s in ["gemm.hip", "pk_dma.h", "pk_kernels.h", "pk_tables.h", "pk_tail_wave.h", "pk_wave.h"]:   # gemm.hip and every header it includes
         with open(os.path.join(CSRC, s), "rb") as f:
             h.update(s.encode() + b"\0" + f.read() + b"\0")
     h.update(" ".join(HIP_FLAGS).encode())

@@ -67,7 +67,7 @@ ViewGen *NewGenRecord(pk_mi355_am_t *am, ArenaRec *a, int views) {
     v = new ViewGen();
     v->serial = 0;
   }
-  v->am = am; v->arena = a; v->live = views; v->current = true;
+  v->am = am; v->arena = a; v->live = views; v->current = true; v->withheld = false;
   g_gens.insert(v);
   return v;
 }
@@ -244,7 +244,12 @@ int BatchRangeStatus(pk_mi355_batch *b) {
   if (b->range_pending) {
     const ExecBufs *eb[2] = {&b->exec, &b->exec2};
     b->range_status = EvalRange(b->am, eb, b->lanes == 2 ? 2 : 1);
-    if (b->range_status) snprintf(b->range_msg, sizeof(b->range_msg), "%s", LastError());
+    if (b->range_status) {
+      snprintf(b->range_msg, sizeof(b->range_msg), "%s", LastError());
+      // views handed out by fetch_all(sync = 0) before this verdict hold withheld results: make them say so
+      std::lock_guard<std::mutex> g(g_arena_mu);
+      if (b->arena && b->arena->cur) b->arena->cur->withheld = true;
+    }
     b->range_pending = false;
   }
   if (b->range_status) return Fail(b->range_status, "%s", b->range_msg);
@@ -443,7 +448,7 @@ int pk_mi355_batch_score(pk_mi355_batch_t *b, float prob_scale, int sync) {
     rc = f16 ? RunLayersF16(am, e, b->d_y2 + c0 * 2 * kNumBins, 2 * kNumBins, rows, true,
                             prob_scale, b->d_ll + c0 * N, N, s, tm, nullptr)
              : RunLayers(am, e, b->d_yt + c0, b->ldy, kNumBins, rows, true, prob_scale,
-                         b->d_ll + c0 * N, N, s, tm, nullptr);
+                         b->d_ll + c0 * N, N, s, tm, nullptr, b->d_yt + (b->ldy - 256));
     if (rc) return rc;
   }
   if (two) {                                   // everything is ordered on b->stream again

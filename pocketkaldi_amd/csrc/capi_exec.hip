@@ -115,8 +115,9 @@ int EvalRange(const pk_mi355_am *am, const ExecBufs *const *bufs, int nbufs) {
 //       otherwise the log-likelihood tail is written to tail_out[row * tail_ld].
 int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t ldq,
               int splice_dim, int rows, bool want_tail, float scale, float *tail_out,
-              int64_t tail_ld, hipStream_t stream, Timer *timer, ExecResult *res) {
+              int64_t tail_ld, hipStream_t stream, Timer *timer, ExecResult *res, const float *splice_zero) {
   const int rows_pad = (int)RoundUp(rows, kTile);
+  if (splice_dim > 0 && !splice_zero) return Fail(PK_MI355_E_INVALID, "spliced input without a zero source");
   if (rows_pad > e.rows_cap) return Fail(PK_MI355_E_INVALID, "chunk larger than workspace");
   const float *blob = am->d_blob;
   const int nl = (int)am->layers.size();
@@ -162,6 +163,10 @@ int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t
           g.P = blob + D.wt_off; g.ldp = D.Npad;
           g.Q = cur; g.ldq = cur_ld;
           g.splice_dim = cur_splice ? splice_dim : 0;
+          if (cur_splice) {
+            g.splice_ctx = am->left + am->right + 1;
+            g.splice_zero = splice_zero;
+          }
           g.bias_on_j = 0;
           g.ldo = e.rows_cap;
           g.tiles_i = D.Npad / kTile; g.tiles_j = rows_pad / kTile;
@@ -454,7 +459,7 @@ int ScoreSingleQueue(pk_mi355_am *am, const pk_matrix_t *feats, bool want_tail, 
     rc = f16 ? RunLayersF16(am, w->exec, w->d_y2 + r0 * 2 * D, 2 * D, rows, want_tail, prob_scale,
                             w->d_out + r0 * N, N, w->stream, nullptr, nullptr)
              : RunLayers(am, w->exec, w->d_yt + r0, w->yt_ld, D, rows, want_tail, prob_scale,
-                         w->d_out + r0 * N, N, w->stream, nullptr, nullptr);
+                         w->d_out + r0 * N, N, w->stream, nullptr, nullptr, w->d_yt + (w->yt_ld - 256));
     if (rc) return rc;
   }
   if (f16 && (rc = CollectRange(w->exec, w->stream))) return rc;
@@ -565,6 +570,7 @@ void pk_decodable_destroy(pk_decodable_t *self) {
 }
 
 float pk_decodable_loglikelihood(pk_decodable_t *self, int frame, int trans_id) {
+  if (IsView(self->am) && GenOf(self->am)->withheld) return NAN;     // results the range check withheld (see fetch_all, sync == 0)
   const int pdf = pk_mi355_am_transition_to_pdf(Untag(self->am), trans_id);
   return self->log_prob.data[(size_t)frame * self->log_prob.nrow + pdf];
 }

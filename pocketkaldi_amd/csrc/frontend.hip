@@ -20,6 +20,7 @@
 #include "pk_dma.h"
 #include "pk_kernels.h"
 #include "pk_logf.h"
+#include "pk_wave.h"
 
 #pragma clang fp contract(off)
 
@@ -39,51 +40,77 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // y[0..511] ARE that array (srfft.cc:296-303 de-interleaves because its recursion wants
 // split arrays; the arithmetic is the same), and every butterfly moves whole complex
 // values, so each LDS access is one 8-byte word.
+// A complex point of the frame by its LDS byte address (a 16-bit half of a packed pair, FftLane): the address goes
+// into the ds instruction as it is -- one vector instruction to unpack a point instead of two (extract the slot
+// byte, shift-and-add the frame's base), 28 fewer per frame over the seven passes.
+typedef f32x2 __attribute__((address_space(3))) *LdsPoint;
+__device__ __forceinline__ LdsPoint PointLo(unsigned pair) { return (LdsPoint)(pair & 0xffffu); }
+__device__ __forceinline__ LdsPoint PointHi(unsigned pair) { return (LdsPoint)(pair >> 16); }
+__device__ __forceinline__ unsigned LdsAddressOf(const void *p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+
 template <int LOGM>
-__device__ __forceinline__ void LButterfly(f32x2 *z, unsigned pts, int n, const float (&tw)[6]) {
+__device__ __forceinline__ void LButterfly(unsigned p01, unsigned p23, int n, const f32x2 (&tw)[3]) {
   constexpr int m = 1 << LOGM, m8 = m / 8;
-  // the LDS slots of points n, n + m/4, n + m/2, n + 3m/4 of the block (FftLane::pts); unpacked per
+  // the LDS addresses of points n, n + m/4 (p01) and n + m/2, n + 3m/4 (p23) of the block (FftLane::pts); unpacked per
   // frame (kept unpacked across the frame loop they cost 40 registers and a wave per SIMD)
-  asm volatile("" : "+v"(pts));
-  const int i0 = pts & 255, i1 = (pts >> 8) & 255, i2 = (pts >> 16) & 255, i3 = pts >> 24;
-  const f32x2 z0 = z[i0], z1 = z[i1], z2 = z[i2], z3 = z[i3];
+  asm volatile("" : "+v"(p01), "+v"(p23));
+  const LdsPoint i0 = PointLo(p01), i1 = PointHi(p01), i2 = PointLo(p23), i3 = PointHi(p23);
+  const f32x2 z0 = *i0, z1 = *i1, z2 = *i2, z3 = *i3;
 
-  float ar = z0[0] + z2[0], br = z0[0] - z2[0];
-  float ai = z0[1] + z2[1], bi = z0[1] - z2[1];
-  float cr = z1[0] + z3[0], dr = z1[0] - z3[0];
-  float ci = z1[1] + z3[1], di = z1[1] - z3[1];
-  z[i0] = f32x2{ar, ai};
-  z[i1] = f32x2{cr, ci};
+  // srfft.cc:163-173: (a, c) = (z0 + z2, z1 + z3) go back to points 0, 1; b = z0 - z2, d = z1 - z3 feed the +-j step.
+  // Everything is kept as the PAIRS the packed fp32 instructions want (one instruction per pair, same roundings):
+  //   x = (r2, q1) = (br - di, bi - dr)      y = (q2, r1) = (bi + dr, br + di)          (srfft.cc:176-188)
+  // with r1 -> re[i2], q1 -> im[i2], r2 -> re[i3], q2 -> im[i3].
+  const f32x2 a = z0 + z2, b = z0 - z2, c = z1 + z3, d = z1 - z3;
+  *i0 = a;
+  *i1 = c;
+  const f32x2 ds = __builtin_shufflevector(d, d, 1, 0);
+  f32x2 x = b - ds;
+  const f32x2 yp = b + ds;
+  f32x2 y = __builtin_shufflevector(yp, yp, 1, 0);
 
-  float r1 = br + di;   // -> re[i2]
-  float q2 = bi + dr;   // -> im[i3]
-  float q1 = bi - dr;   // -> im[i2]
-  float r2 = br - di;   // -> re[i3]
-
-  if (LOGM >= 3 && n != 0) {
-    if (n == m8) {
-      const float sq = 0.70710678118654752440;   // srfft.cc:41-43, narrowed like `float sqhalf`
-      float t1 = sq * (r1 + q1);
-      q1 = sq * (q1 - r1);
-      r1 = t1;
-      float t2 = sq * (q2 - r2);
-      q2 = -sq * (r2 + q2);
-      r2 = t2;
-    } else if (LOGM >= 4) {
-      const float cn = tw[0], spcn = tw[1], smcn = tw[2];
-      const float c3n = tw[3], spc3n = tw[4], smc3n = tw[5];
-      float t2 = cn * (r1 + q1);
-      float t1 = spcn * r1 + t2;
-      r1 = smcn * q1 + t2;
-      q1 = t1;
-      t2 = c3n * (r2 + q2);
-      t1 = spc3n * r2 + t2;
-      r2 = smc3n * q2 + t2;
-      q2 = t1;
+  // srfft.cc:198-222, the twiddles.  The general form runs on every lane of the butterfly; the lanes of the two special
+  // positions then overwrite its result under their own execution masks (n = m/8: the +-sqrt(1/2) form; n = 0: no
+  // twiddle) -- three packed instructions and two moves, written out because hipcc turns the same thing as C++ into
+  // either nested branches with a dozen register copies at the joins, or sixteen selects.
+  //   general:  t2 = (c3n, cn) (x + y);  o1 = (smc3n, spcn) y + t2 = (r2', q1');  o2 = (spc3n, smcn) x + t2 = (q2', r1')
+  //   n = m/8:  o1 = sq (q2 - r2, q1 - r1);  o2 = (-sq, sq) (r2 + q2, q1 + r1)
+  if (LOGM >= 3) {
+    const f32x2 s = x + y;                       // (r2 + q2, q1 + r1)
+    f32x2 o1 = x, o2 = y;
+    if (LOGM >= 4) {
+      const f32x2 t2 = tw[0] * s;
+      o1 = tw[1] * y + t2;
+      o2 = tw[2] * x + t2;
     }
+    const float sq = 0.70710678118654752440;     // srfft.cc:41-43, narrowed like `float sqhalf`
+    const f32x2 sq2 = f32x2{sq, sq};
+    const unsigned long long at_m8 = __builtin_amdgcn_ballot_w64(n == m8);
+    const unsigned long long at_0 = __builtin_amdgcn_ballot_w64(LOGM >= 4 && n == 0);    // (LOGM = 3: o already is (x, y))
+    unsigned long long saved;
+    f32x2 u;
+    asm("s_and_saveexec_b64 %[sv], %[m8]\n\t"
+        "v_pk_add_f32 %[u], %[y], %[x] neg_lo:[0,1] neg_hi:[1,0]\n\t"       // (q2 - r2, q1 - r1)
+        "v_pk_mul_f32 %[o1], %[u], %[sq2]\n\t"
+        "v_pk_mul_f32 %[o2], %[s], %[sq2] neg_lo:[0,1]\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_and_saveexec_b64 %[sv], %[m0]\n\t"
+        "v_mov_b64 %[o1], %[x]\n\t"
+        "v_mov_b64 %[o2], %[y]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [o1] "+v"(o1), [o2] "+v"(o2), [u] "=&v"(u), [sv] "=&s"(saved)
+        : [x] "v"(x), [y] "v"(y), [s] "v"(s), [sq2] "s"(sq2), [m8] "s"(at_m8), [m0] "s"(at_0)
+        : "vcc");
+    x = o1;
+    y = o2;
   }
-  z[i2] = f32x2{r1, q1};
-  z[i3] = f32x2{r2, q2};
+  // re[i2] = r1', im[i2] = q1', re[i3] = r2', im[i3] = q2': the halves sit in different register pairs, and
+  // ds_write2_b32 takes its two words from two registers -- as one 8-byte store each pair would first be regrouped by
+  // three moves a pass.  (WaveSync follows every pass: its lgkmcnt(0) covers these.)
+  asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(i2), "v"(y[1]), "v"(x[1]) : "memory");
+  asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(i3), "v"(x[0]), "v"(y[0]) : "memory");
 }
 
 // The constant tables of the front-end, copied once per workgroup into LDS (the
@@ -92,11 +119,14 @@ __device__ __forceinline__ void LButterfly(f32x2 *z, unsigned pts, int n, const 
 typedef FrontendLdsImage LdsTables;
 
 // Per-wave work area: one frame.
-struct FrameLds {
-  float x[kFrameLength];       // DC-removed samples (pre-emphasis neighbour)
+struct alignas(16) FrameLds {
+  float x[kFrameLength];       // general float input only: the samples in order, for the sequential DC sum
   f32x2 z[kFftCplx];           // the 256 complex points (= the 512 windowed samples)
-  float pw[kFftCplx + 4];
+  float pw[kFftCplx + 4];      // power spectrum (+ slack: a mel padding tap may read up to three slots behind bin 256)
 };
+// x and z are dead once the power spectrum is written: the mel products go there
+static_assert(sizeof(float) * kMelProducts <= sizeof(float) * kFrameLength + sizeof(f32x2) * kFftCplx, "mel products fit in x + z");
+static_assert((sizeof(float) * kFrameLength) % 16 == 0 && sizeof(FrameLds) % 16 == 0, "16-byte rows");
 
 // The four waves of a workgroup work on different frames and never exchange data, so
 // the barrier between FFT passes is wave-local: LDS operations of one wave complete in
@@ -125,17 +155,21 @@ __device__ __forceinline__ int FftSlot(int i) {
   return i ^ x;
 }
 
+// Points are held as LDS byte addresses of THIS wave's frame, two 16-bit halves per register.
 struct FftLane {
-  unsigned pts[kNumPasses - 1];      // passes LOGM = 8..2: the slots of this lane's four points, a byte each
+  unsigned pts[kNumPasses - 1][2];   // passes LOGM = 8..2: this lane's four points (n, n + m/4 | n + m/2, n + 3m/4)
   unsigned active;                   // bit p: this lane has a butterfly in pass p; bits 8, 9: a two-point block
-  float tw[5][6];                    // LOGM = 8..4: cn, -(s+c), s-c, c3n, -(s3+c3), s3-c3 (srfft.cc:45-93)
-  unsigned two;                      // slots of the two-point blocks (srfft.cc:140-150): a0, a0 + 1, a1, a1 + 1
-  unsigned post;                     // post-pass: slots of bins k = 1 + lane + 64 r and 256 - k, bit-reversed
+  f32x2 tw[5][3];                    // LOGM = 8..4, as the pairs the butterfly multiplies by (srfft.cc:45-93):
+                                     // (c3n, cn), (s3-c3, -(s+c)), (-(s3+c3), s-c)
+  unsigned two[2];                   // the two-point blocks (srfft.cc:140-150): (a0, a0 + 1) of block lane, of block lane + 64
+  unsigned post[2];                  // post-pass: bins k = 1 + lane + 64 r and 256 - k, bit-reversed
   float kre[2], kim[2];              // exp(-2 pi i k / 512) as srfft.cc:385-394 builds it
-  unsigned stage;                    // slots of the points lane + 64 r the lane writes when it windows a frame
+  unsigned stage[2];                 // the points lane + 64 r the lane writes when it windows a frame (r = 0, 1 | 2, 3)
 };
 
-__device__ __forceinline__ void MakeFftLane(FftLane &c, int lane, const LdsTables &tab) {
+__device__ __forceinline__ void MakeFftLane(FftLane &c, int lane, const LdsTables &tab, const f32x2 *z) {
+  const unsigned zb = LdsAddressOf(z);
+  auto at = [&](int i) { return zb + 8u * (unsigned)FftSlot(i); };       // (the whole LDS of these kernels is below 64 KiB)
   c.active = 0;
 #pragma unroll
   for (int pass = 0; pass < kNumPasses - 1; ++pass) {
@@ -144,43 +178,44 @@ __device__ __forceinline__ void MakeFftLane(FftLane &c, int lane, const LdsTable
     const int first = tab.pass_start[pass];
     const int nblk = tab.pass_start[pass + 1] - first;
     const int b = lane / q, n = lane % q;
-    c.pts[pass] = 0;
+    c.pts[pass][0] = c.pts[pass][1] = 0;
     if (b < nblk) {
       const int i0 = tab.blk_off[first + b] + n;
-      c.pts[pass] = FftSlot(i0) | (FftSlot(i0 + q) << 8) | (FftSlot(i0 + 2 * q) << 16) | ((unsigned)FftSlot(i0 + 3 * q) << 24);
+      c.pts[pass][0] = at(i0) | (at(i0 + q) << 16);
+      c.pts[pass][1] = at(i0 + 2 * q) | (at(i0 + 3 * q) << 16);
       c.active |= 1u << pass;
     }
     if (logm >= 4) {
-      const float *tw = tab.tw + tab.tw_off[logm];
-#pragma unroll
-      for (int j = 0; j < 6; ++j) c.tw[pass][j] = tw[j * q + n];
+      const float *tw = tab.tw + tab.tw_off[logm];      // six arrays of q: cn, -(s+c), s-c, c3n, -(s3+c3), s3-c3
+      c.tw[pass][0] = f32x2{tw[3 * q + n], tw[0 * q + n]};
+      c.tw[pass][1] = f32x2{tw[5 * q + n], tw[1 * q + n]};
+      c.tw[pass][2] = f32x2{tw[4 * q + n], tw[2 * q + n]};
     }
   }
   const int first = tab.pass_start[kNumPasses - 1];
   const int nblk = tab.pass_start[kNumPasses] - first;
-  c.two = 0; c.post = 0; c.stage = 0;
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const int b = lane + kWave * r;
+    c.two[r] = 0;
     if (b < nblk) {
       const int off = tab.blk_off[first + b];
-      c.two |= (unsigned)(FftSlot(off) | (FftSlot(off + 1) << 8)) << (16 * r);
+      c.two[r] = at(off) | (at(off + 1) << 16);
       c.active |= 1u << (8 + r);
     }
     const int k = 1 + lane + kWave * r;
-    c.post |= (unsigned)(FftSlot(tab.bitrev[k]) | (FftSlot(tab.bitrev[kFftCplx - k]) << 8)) << (16 * r);
+    c.post[r] = at(tab.bitrev[k]) | (at(tab.bitrev[kFftCplx - k]) << 16);
     c.kre[r] = tab.post_re[k];
     c.kim[r] = tab.post_im[k];
+    c.stage[r] = at(lane + kWave * 2 * r) | (at(lane + kWave * (2 * r + 1)) << 16);
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) c.stage |= (unsigned)FftSlot(lane + kWave * r) << (8 * r);
 }
 
 template <int LOGM>
-__device__ __forceinline__ void FftPass(f32x2 *z, int lane, const FftLane &c) {
+__device__ __forceinline__ void FftPass(int lane, const FftLane &c) {
   constexpr int pass = kLogCplx - LOGM;
   constexpr int q = (1 << LOGM) / 4;
-  if (c.active & (1u << pass)) LButterfly<LOGM>(z, c.pts[pass], lane % q, c.tw[pass < 5 ? pass : 0]);
+  if (c.active & (1u << pass)) LButterfly<LOGM>(c.pts[pass][0], c.pts[pass][1], lane % q, c.tw[pass < 5 ? pass : 0]);
   WaveSync();
 }
 
@@ -207,21 +242,21 @@ __device__ __forceinline__ void CopyTablesToLds(LdsTables &tab, const FrontendTa
 
 // srfft.cc:95-237: the 256-point complex split-radix DIF on the interleaved frame in LDS, one
 // wave, as eight passes over the block schedule; output in bit-reversed order.
-__device__ __forceinline__ void ComplexFft256(f32x2 *s_z, int lane, const FftLane &c) {
-  FftPass<8>(s_z, lane, c);
-  FftPass<7>(s_z, lane, c);
-  FftPass<6>(s_z, lane, c);
-  FftPass<5>(s_z, lane, c);
-  FftPass<4>(s_z, lane, c);
-  FftPass<3>(s_z, lane, c);
-  FftPass<2>(s_z, lane, c);
+__device__ __forceinline__ void ComplexFft256(int lane, const FftLane &c) {
+  FftPass<8>(lane, c);
+  FftPass<7>(lane, c);
+  FftPass<6>(lane, c);
+  FftPass<5>(lane, c);
+  FftPass<4>(lane, c);
+  FftPass<3>(lane, c);
+  FftPass<2>(lane, c);
 #pragma unroll
   for (int r = 0; r < 2; ++r) {   // two-point blocks, srfft.cc:140-150
     if (c.active & (1u << (8 + r))) {
-      const int a0 = (c.two >> (16 * r)) & 255, a1 = (c.two >> (16 * r + 8)) & 255;
-      const f32x2 u0 = s_z[a0], u1 = s_z[a1];
-      s_z[a0] = f32x2{u0[0] + u1[0], u0[1] + u1[1]};
-      s_z[a1] = f32x2{u0[0] - u1[0], u0[1] - u1[1]};
+      const LdsPoint a0 = PointLo(c.two[r]), a1 = PointHi(c.two[r]);
+      const f32x2 u0 = *a0, u1 = *a1;
+      *a0 = f32x2{u0[0] + u1[0], u0[1] + u1[1]};
+      *a1 = f32x2{u0[0] - u1[0], u0[1] - u1[1]};
     }
   }
   WaveSync();
@@ -231,8 +266,8 @@ __device__ __forceinline__ void ComplexFft256(f32x2 *s_z, int lane, const FftLan
 // srfft.cc:389-436, with the bit-reversed read of srfft.cc:239-265 folded in.  (a_re, a_im) is bin k,
 // (o_re, o_im) bin 256 - k.
 struct RealBins { float a_re, a_im, o_re, o_im; };
-__device__ __forceinline__ RealBins RealPostPass(const f32x2 *s_z, const FftLane &c, int r) {
-  const f32x2 zk = s_z[(c.post >> (16 * r)) & 255], zd = s_z[(c.post >> (16 * r + 8)) & 255];
+__device__ __forceinline__ RealBins RealPostPass(const FftLane &c, int r) {
+  const f32x2 zk = *PointLo(c.post[r]), zd = *PointHi(c.post[r]);
   const float bk_re = zk[0], bk_im = zk[1];
   const float bd_re = zd[0], bd_im = zd[1];
   const float kre = c.kre[r], kim = c.kim[r];
@@ -253,10 +288,19 @@ __device__ __forceinline__ RealBins RealPostPass(const f32x2 *s_z, const FftLane
 
 constexpr int kFbankWaves = 4;
 
+// One tap of a mel triangle: w * p, one rounding (vector.cc:252-262).  v_mul_legacy_f32 is v_mul_f32 except that
+// 0 * x = 0 for EVERY x: a padding tap (weight 0) reads a power-spectrum slot outside its triangle, and must
+// contribute +0 even when that slot is inf or NaN; a real tap's weight is never zero (fbank.cc:141: strict inequalities).
+__device__ __forceinline__ float MelProduct(float w, float p) {
+  float r;
+  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(w), "v"(p));
+  return r;
+}
+
 // Each wave of a workgroup walks frames t = blockIdx.x * 4 + wave, + gridDim.x * 4, ...
 // of utterance blockIdx.y.
 template <typename SampleT>
-__global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
+__global__ __launch_bounds__(kWave * kFbankWaves, 4) void FbankKernel(
     const SampleT *__restrict__ wave_pcm, UttLayout utts, const FrontendTables *__restrict__ gtab,
     float *__restrict__ raw) {
   __shared__ LdsTables tab;
@@ -268,20 +312,19 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
 
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  FftLane fc;
-  MakeFftLane(fc, lane, tab);
-  float win_e[4], win_o[4];                        // the Hamming window at this lane's pairs p = lane + 64 r
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int pidx = lane + kWave * r;
-    win_e[r] = 2 * pidx + 1 < kFrameLength ? tab.window[2 * pidx] : 0.0f;
-    win_o[r] = 2 * pidx + 1 < kFrameLength ? tab.window[2 * pidx + 1] : 0.0f;
-  }
-  const int mel_off = lane < kNumBins ? tab.mel_off[lane] : 0, mel_len = lane < kNumBins ? tab.mel_len[lane] : 0;
-  const float *mel_w = tab.mel_w + (lane < kNumBins ? tab.mel_base[lane] : 0);
   FrameLds &fr = frames[wv];
+  FftLane fc;
+  MakeFftLane(fc, lane, tab, fr.z);
   float *s_x = fr.x, *s_pow = fr.pw;
   f32x2 *s_z = fr.z;
+  // mel stage (pk_tables.h: kMelProducts): this lane forms products 4 lane + e, 256 + 4 lane + e (e < 4) and 512 + lane;
+  // lanes < 40 then add the products of their bin in order
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  float *s_prod = fr.x;
+  const float *mel_p0 = s_pow + tab.mel_pgrp[lane], *mel_p1 = s_pow + tab.mel_pgrp[64 + lane];
+  const float *mel_p2 = s_pow + tab.mel_pgrp[128 + (lane >> 2)] + (lane & 3);
+  const float *mel_run = s_prod + (lane < kNumBins ? tab.mel_pbase[lane] : 0);
+  const int mel_plen = lane < kNumBins ? tab.mel_plen[lane] : 0;
   const int utt = blockIdx.y;
   const int T = utts.num_frames[utt];
   const SampleT *w0 = wave_pcm + utts.wave_off[utt];
@@ -317,9 +360,10 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
     for (int r = 0; r < 4; ++r) {
       xe[r] = static_cast<float>(cur_e[r]);
       xo[r] = static_cast<float>(cur_o[r]);
-      // integer-valued samples of at most 16 bits: any summation order is exact
-      exact = exact && (fabsf(xe[r]) <= 32768.0f) && (xe[r] == truncf(xe[r]))
-                    && (fabsf(xo[r]) <= 32768.0f) && (xo[r] == truncf(xo[r]));
+      // integer-valued samples of at most 16 bits: any summation order is exact (int16 input: by type)
+      if (!std::is_same<SampleT, int16_t>::value)
+        exact = exact && (fabsf(xe[r]) <= 32768.0f) && (xe[r] == truncf(xe[r]))
+                      && (fabsf(xo[r]) <= 32768.0f) && (xo[r] == truncf(xo[r]));
     }
 
     // ---- fbank.cc:48-52: DC offset = sequential float sum / 400.
@@ -327,10 +371,8 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
     if (__all(exact)) {
       // 400 integers of magnitude <= 2^15: every partial sum is an integer below
       // 2^24, so the tree sum equals the reference's sequential sum bit for bit.
-      float p = ((xe[0] + xo[0]) + (xe[1] + xo[1])) + ((xe[2] + xo[2]) + (xe[3] + xo[3]));
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
-      sum = p;
+      const float p = ((xe[0] + xo[0]) + (xe[1] + xo[1])) + ((xe[2] + xo[2]) + (xe[3] + xo[3]));
+      sum = TwWaveSum(p);
     } else {
       // general float input: keep the reference's order (one lane, 400 adds)
 #pragma unroll
@@ -340,8 +382,10 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
       }
       WaveSync();
       float s = 0;
-      if (lane == 0)
+      if (lane == 0) {
+#pragma unroll 8        // (a rare path: its temporaries must not set the kernel's register count)
         for (int i = 0; i < kFrameLength; ++i) s += s_x[i];
+      }
       sum = __shfl(s, 0);
       WaveSync();
     }
@@ -361,19 +405,21 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
       // sample 2p - 1 = the odd sample of pair p - 1: lane - 1 of the same r, or lane 63 of r - 1
       float prev_e = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, xo[r]), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
       if (lane == 0) prev_e = r == 0 ? xe[0] : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xo[r > 0 ? r - 1 : 0]), 63));
+      // (the Hamming window at samples 2p, 2p + 1: one 8-byte LDS read a frame instead of eight registers all along)
+      const f32x2 win = *reinterpret_cast<const f32x2 *>(tab.window + 2 * (pidx < kFrameLength / 2 ? pidx : 0));
       float ye = 0.0f, yo = 0.0f;
       if (2 * pidx + 1 < kFrameLength) {
         ye = static_cast<float>(static_cast<double>(xe[r]) - 0.97 * static_cast<double>(prev_e));
-        ye *= win_e[r];
+        ye *= win[0];
         yo = static_cast<float>(static_cast<double>(xo[r]) - 0.97 * static_cast<double>(xe[r]));
-        yo *= win_o[r];
+        yo *= win[1];
       }
-      s_z[(fc.stage >> (8 * r)) & 255] = f32x2{ye, yo};
+      *((r & 1) ? PointHi(fc.stage[r >> 1]) : PointLo(fc.stage[r >> 1])) = f32x2{ye, yo};
     }
     WaveSync();
 
     // ---- srfft.cc:95-237 as passes over the block schedule
-    ComplexFft256(s_z, lane, fc);
+    ComplexFft256(lane, fc);
 
     // ---- bit-reversed read (srfft.cc:239-265), real post-pass (srfft.cc:389-436)
     // and power spectrum (fbank.cc:193-211) fused: bin k and its partner 256-k.
@@ -381,7 +427,7 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
     for (int r = 0; r < 2; ++r) {
       const int k = 1 + lane + kWave * r;            // 1..128
       const int kd = kFftCplx - k;
-      const RealBins rb = RealPostPass(s_z, fc, r);
+      const RealBins rb = RealPostPass(fc, r);
       s_pow[k] = rb.a_re * rb.a_re + rb.a_im * rb.a_im;
       if (kd != k) s_pow[kd] = rb.o_re * rb.o_re + rb.o_im * rb.o_im;
     }
@@ -393,19 +439,39 @@ __global__ __launch_bounds__(kWave * kFbankWaves) void FbankKernel(
     }
     WaveSync();
 
-    // ---- fbank.cc:165-184 (sequential float dot per bin, vector.cc:252-262),
-    // floor FLT_EPSILON and log (fbank.cc:244-245; the C library's logf, pk_logf.h)
-    if (lane < kNumBins) {
-      // (two taps per trip: each pair of neighbouring operands is one ds_read2_b32)
-      float e = 0.0f;
-      const float *pw = s_pow + mel_off;
-      int j = 0;
-      for (; j + 1 < mel_len; j += 2) {
-        const float w0 = mel_w[j], w1 = mel_w[j + 1], p0 = pw[j], p1 = pw[j + 1];
-        e += w0 * p0;
-        e += w1 * p1;
+    // ---- fbank.cc:165-184: E[b] = sum_j w_b[j] * P[off_b + j], a sequential float dot per bin (vector.cc:252-262).
+    // The products first, nine per lane over all 64 lanes (a product is one rounding whichever lane forms it) ...
+    {
+      const f32x4 w0 = *reinterpret_cast<const f32x4 *>(tab.mel_wprod + 4 * lane);
+      const f32x4 w1 = *reinterpret_cast<const f32x4 *>(tab.mel_wprod + 256 + 4 * lane);
+      const float w2 = tab.mel_wprod[512 + lane];
+      f32x4 q0, q1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        q0[e] = MelProduct(w0[e], mel_p0[e]);
+        q1[e] = MelProduct(w1[e], mel_p1[e]);
       }
-      if (j < mel_len) e += mel_w[j] * pw[j];
+      *reinterpret_cast<f32x4 *>(s_prod + 4 * lane) = q0;
+      *reinterpret_cast<f32x4 *>(s_prod + 256 + 4 * lane) = q1;
+      s_prod[512 + lane] = MelProduct(w2, mel_p2[0]);
+    }
+    WaveSync();
+    // ... then the additions in the reference's order, one lane per bin (the run is padded with +0 products to a
+    // multiple of four); floor FLT_EPSILON and log (fbank.cc:244-245; the C library's logf, pk_logf.h)
+    if (lane < kNumBins) {
+      float e = 0.0f;
+      // (straight-line: which lanes take part in group g does not change from frame to frame -- the comparisons are
+      // loop-invariant execution masks, the groups cost their four additions and nothing else)
+#pragma unroll
+      for (int g = 0; g < kMelMaxPadded / 4; ++g) {
+        if (4 * g < mel_plen) {
+          const f32x4 q = *reinterpret_cast<const f32x4 *>(mel_run + 4 * g);
+          e += q[0];
+          e += q[1];
+          e += q[2];
+          e += q[3];
+        }
+      }
       if (e < 1.1920928955078125e-07f) e = 1.1920928955078125e-07f;
       out0[(int64_t)t * kNumBins + lane] = LogfRestated(e, tab.logf_tab);
     }
@@ -652,18 +718,18 @@ __global__ __launch_bounds__(kWave) void Srfft512TestKernel(const float *__restr
   __syncthreads();
   const int lane = threadIdx.x;
   FftLane fc;
-  MakeFftLane(fc, lane, tab);
+  MakeFftLane(fc, lane, tab, s_z);
   for (int f = blockIdx.x; f < n; f += gridDim.x) {
     const float *x = frames + (int64_t)f * kFftSize;
     float *y = out + (int64_t)f * kFftSize;
     for (int i = lane; i < kFftCplx; i += kWave) s_z[FftSlot(i)] = f32x2{x[2 * i], x[2 * i + 1]};
     WaveSync();
-    ComplexFft256(s_z, lane, fc);
+    ComplexFft256(lane, fc);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int k = 1 + lane + kWave * r;
       const int kd = kFftCplx - k;
-      const RealBins rb = RealPostPass(s_z, fc, r);
+      const RealBins rb = RealPostPass(fc, r);
       y[2 * k] = rb.a_re;
       y[2 * k + 1] = rb.a_im;
       if (kd != k) { y[2 * kd] = rb.o_re; y[2 * kd + 1] = rb.o_im; }

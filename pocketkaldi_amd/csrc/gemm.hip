@@ -91,7 +91,10 @@ __device__ __forceinline__ void IssuePiece(const GemmArgs &a, const float *__res
     const int row = wave * 4 + (piece - S) * G::kPieceRows;
     const int k = k0 + row + lane / G::kLanesPerRow;
     const int c = k / a.splice_dim, d = k - c * a.splice_dim;
-    DmaVectorAddr(qs + row * G::kBT, qg + (int64_t)d * a.ldq + c + (lane % G::kLanesPerRow) * 4);
+    // rows past the last context frame (K is padded to the slab) come from zeros, not from the frame behind the
+    // context: their weights are zero, but 0 * NaN is NaN, and the reference has no such row
+    const float *src = c < a.splice_ctx ? qg + (int64_t)d * a.ldq + c : a.splice_zero;
+    DmaVectorAddr(qs + row * G::kBT, src + (lane % G::kLanesPerRow) * 4);
   }
 }
 
@@ -266,10 +269,17 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
   auto issue_splice = [&](int slot_to, int p) {       // p in [S, 2 S)
     const int j = p - S;
     const int row = wave * 4 + j * G::kPieceRows;
+#ifdef PK_EXP_SPLICE_ALIGNED
+    const int d0 = sd[j], c0 = sc[j] & ~3;            // TIMING ONLY (wrong results): every shift a multiple of four columns = 16-byte aligned rows
+#else
     const int d0 = sd[j], c0 = sc[j];
+#endif
     const bool wrap = d0 + 1 == a.splice_dim;
-    const int64_t off0 = (int64_t)d0 * a.ldq + c0;
-    const int64_t off1 = wrap ? (int64_t)c0 + 1 : off0 + a.ldq;
+    // (operand rows past the last context frame -- K is padded to the slab -- come from zeros: see IssuePiece)
+    const int64_t zoff = a.splice_zero - qg;
+    const int64_t in0 = (int64_t)d0 * a.ldq + c0;
+    const int64_t off0 = c0 < a.splice_ctx ? in0 : zoff;
+    const int64_t off1 = (wrap ? c0 + 1 : c0) < a.splice_ctx ? (wrap ? (int64_t)c0 + 1 : in0 + a.ldq) : zoff;
     const int64_t lo = off1 < off0 ? off1 : off0;
     const uint32_t dist = (uint32_t)((off1 < off0 ? off0 - off1 : off1 - off0) * sizeof(float));
     const bool second = lane >= G::kLanesPerRow;       // this lane fetches row k + 1
@@ -403,7 +413,11 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
         // write-through (agent-coherent) store: the rows are read back by whichever workgroup completes the row
         // tile, possibly on another XCD, whose L2 this store must not bypass silently
         const f32x2 vv = f32x2{v[0], v[S - 1]};
+#ifdef PK_EXP_TAIL_NT
+        asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" ::"v"(dst), "v"(vv) : "memory");
+#else
         asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(vv) : "memory");
+#endif
       } else if (S == 2) {
         *reinterpret_cast<f32x2 *>(dst) = f32x2{v[0], v[S - 1]};
       } else {

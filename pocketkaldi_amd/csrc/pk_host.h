@@ -254,9 +254,11 @@ float RangeMax(const ExecBufs &e, int l);
 int EvalRange(const pk_mi355_am *am, const ExecBufs *const *bufs, int nbufs);
 int CalibrateStep(pk_mi355_am *am, const ExecBufs &e, std::vector<char> *settled);
 
+// splice_zero (spliced input only): >= 128 zero floats in the same allocation as q0 -- the last 256 columns of
+// feature row 0 of every Yt this library allocates are never written
 int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t ldq,
               int splice_dim, int rows, bool want_tail, float scale, float *tail_out,
-              int64_t tail_ld, hipStream_t stream, Timer *timer, ExecResult *res);
+              int64_t tail_ld, hipStream_t stream, Timer *timer, ExecResult *res, const float *splice_zero = nullptr);
 int RunLayersF16(const pk_mi355_am *am, const ExecBufs &e, const _Float16 *x, int64_t ldx, int rows,
                  bool want_tail, float scale, float *tail_out,
                  int64_t tail_ld, hipStream_t stream, Timer *timer, ExecResult *res);
@@ -272,6 +274,8 @@ struct alignas(64) ViewGen {
   ArenaRec *arena;       // valid while `current`
   int live;              // views of this generation not yet destroyed
   bool current;          // the batch's latest fetch_all
+  bool withheld;         // f16 modes: the views were handed out (sync == 0) before the score call's range verdict, and the
+                         // verdict was PK_MI355_E_RANGE: pk_decodable_loglikelihood on them returns NaN
   unsigned serial;       // 0..31, part of the handle
 };
 inline bool IsView(const pk_mi355_am_t *am) { return (reinterpret_cast<uintptr_t>(am) & 1u) != 0; }

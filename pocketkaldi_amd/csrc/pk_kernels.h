@@ -68,6 +68,8 @@ struct GemmArgs {
   int64_t ldq;
   int K;
   int splice_dim;
+  int splice_ctx = 0;            // splice: context frames (operand rows k >= splice_ctx * splice_dim are padding)
+  const float *splice_zero = nullptr;   // splice: >= 128 zero floats within 4 GB of Q (the source of the padding rows)
   const float *bias;   // indexed by i (bias_on_j = 0) or j (bias_on_j = 1); padded
   int bias_on_j;
   int relu;

@@ -157,12 +157,19 @@ int BuildFrontendTables(FrontendTables *t) {
   memcpy(L.tw, t->tw, sizeof(L.tw));
   memcpy(L.post_re, t->post_re, sizeof(L.post_re));
   memcpy(L.post_im, t->post_im, sizeof(L.post_im));
-  memcpy(L.mel_w, t->mel_packed, sizeof(L.mel_w));
-  for (int i = 0; i < kNumBins; ++i) {
-    if (t->mel_off[i] > 32767 || t->mel_len[i] > 32767 || t->mel_base[i] > 32767) return -1;
-    L.mel_off[i] = (short)t->mel_off[i];
-    L.mel_len[i] = (short)t->mel_len[i];
-    L.mel_base[i] = (short)t->mel_base[i];
+  // the mel stage in product order (pk_tables.h: kMelProducts)
+  memset(L.mel_wprod, 0, sizeof(L.mel_wprod));
+  memset(L.mel_pgrp, 0, sizeof(L.mel_pgrp));
+  int prod = 0;
+  for (int b = 0; b < kNumBins; ++b) {
+    const int len = t->mel_len[b], padded = (len + 3) / 4 * 4;
+    // (a padding tap reads a power-spectrum slot behind the triangle: it must exist -- pw[] has kFftCplx + 4 of them)
+    if (prod + padded > kMelProducts || padded > kMelMaxPadded || t->mel_off[b] + padded > kFftCplx + 4) return -6;
+    L.mel_pbase[b] = (short)prod;
+    L.mel_plen[b] = (short)padded;
+    for (int j = 0; j < len; ++j) L.mel_wprod[prod + j] = t->mel_packed[t->mel_base[b] + j];
+    for (int j = 0; j < padded; j += 4) L.mel_pgrp[(prod + j) / 4] = (short)(t->mel_off[b] + j);
+    prod += padded;
   }
   for (int i = 0; i <= kLogCplx; ++i) L.tw_off[i] = (short)t->tw_off[i];
   for (int i = 0; i <= kNumPasses; ++i) L.pass_start[i] = (short)t->pass_start[i];

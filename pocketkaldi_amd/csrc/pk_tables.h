@@ -35,6 +35,12 @@ constexpr int kTwFloats = 6 * (4 + 8 + 16 + 32 + 64);
 
 constexpr int kMelMaxLen = 64;         // longest triangle (checked at build time)
 constexpr int kMelPacked = 640;        // all triangles back to back (sum of lengths, checked)
+// The mel stage as the kernel runs it: every tap's product w[j] * P[off + j] (fbank.cc:165-184 -> vector.cc:252-262)
+// is formed once, by any lane -- a product is one rounding wherever it is computed -- and only the additions keep the
+// reference's order, one lane per bin.  Products are laid out bin after bin, each bin's run padded to a multiple of
+// four with zero-weight taps (e + (+0) = e), so that a group of four products never straddles two bins: 9 per lane.
+constexpr int kMelProducts = 576;      // >= sum of the padded lengths (checked); 64 lanes x (4 + 4 + 1)
+constexpr int kMelMaxPadded = 32;      // longest padded run (checked): the kernel adds it in eight straight-line groups
 
 // What the front-end kernels keep in LDS, in the layout they keep it in: built once on the host
 // and copied flat, 16 bytes per lane (ten separate table copies, each a round trip to L2, were a
@@ -45,10 +51,10 @@ struct alignas(16) FrontendLdsImage {
   float tw[kTwFloats];
   float post_re[kFftCplx / 2 + 1];
   float post_im[kFftCplx / 2 + 1];
-  float mel_w[kMelPacked];
-  short mel_off[kNumBins];
-  short mel_len[kNumBins];
-  short mel_base[kNumBins];
+  float mel_wprod[kMelProducts];       // tap weights in product order (padding taps: 0)
+  short mel_pgrp[kMelProducts / 4];    // FFT bin of the first tap of product group q (products 4 q .. 4 q + 3: consecutive bins)
+  short mel_pbase[kNumBins];           // first product of bin b (a multiple of four)
+  short mel_plen[kNumBins];            // its padded length
   short tw_off[kLogCplx + 1];
   short pass_start[kNumPasses + 1];
   unsigned char blk_off[kMaxBlocks + 1];

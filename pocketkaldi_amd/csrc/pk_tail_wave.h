@@ -19,35 +19,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pk_wave.h"
+
 namespace pkmi {
 
 typedef float twf4 __attribute__((ext_vector_type(4)));
 typedef unsigned int twu4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTailWaveMaxChunks = 32;          // 32 x 64 lanes x 4 = 8 192 columns at most
-
-// Wave-wide reductions on the vector ALU (DPP row operations; the result is taken from lane 63 and handed to every
-// lane as a scalar): no LDS permutes, whose six dependent round trips per reduction were a quarter of a row's time.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float TwDpp(float x, float identity) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, false));
-}
-template <typename Op>
-__device__ __forceinline__ float TwWaveReduce(float v, Op op, float identity) {
-  v = op(v, TwDpp<0xB1, 0xf>(v, identity));      // quad_perm [1, 0, 3, 2]
-  v = op(v, TwDpp<0x4E, 0xf>(v, identity));      // quad_perm [2, 3, 0, 1]
-  v = op(v, TwDpp<0x141, 0xf>(v, identity));     // row_half_mirror
-  v = op(v, TwDpp<0x140, 0xf>(v, identity));     // row_mirror
-  v = op(v, TwDpp<0x142, 0xa>(v, identity));     // row_bcast:15 into rows 1 and 3
-  v = op(v, TwDpp<0x143, 0xc>(v, identity));     // row_bcast:31 into rows 2 and 3
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-__device__ __forceinline__ float TwWaveMax(float v) {
-  return TwWaveReduce(v, [](float a, float b) { return fmaxf(a, b); }, -INFINITY);
-}
-__device__ __forceinline__ float TwWaveSum(float v) {
-  return TwWaveReduce(v, [](float a, float b) { return a + b; }, 0.0f);
-}
 
 // Rows first, first + step, ... of `in` (row r at in + r * ld_in; with SC1 the whole block must lie within 2 GB of
 // `in`), `iters` of them per wave -- the SAME count for every wave of the workgroup (rows >= rows_end are skipped,
@@ -103,7 +82,11 @@ __device__ __forceinline__ void TailWaveRows(const float *__restrict__ in, int64
 #pragma unroll
   for (int c = 0; c < C; ++c) qc[c] = (q0 + 64 * c < n4) ? q0 + 64 * c : n4 - 1;
   auto load = [&](int row, int c) -> twf4 {
+#ifdef PK_EXP_TAIL_NT
+    if (SC1) return __builtin_bit_cast(twf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)row * pitch + qc[c] * 16, 0, 18 /* sc1 nt */));
+#else
     if (SC1) return __builtin_bit_cast(twf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)row * pitch + qc[c] * 16, 0, 16 /* sc1 */));
+#endif
     return *reinterpret_cast<const twf4 *>(in + (int64_t)row * ld_in + qc[c] * 4);
   };
   twf4 v[C], nv[C];

@@ -120,6 +120,14 @@ def test_saturation_is_reported_not_clamped_quietly(prec):
         bs.score(0.1)
     with pytest.raises(pk.PkError, match="saturated"):
         bs.fetch_all()
+    # views handed out BEFORE the verdict (sync = 0) are voided by it: loglikelihood answers NaN
+    bs.score(0.1, sync=False)
+    early = bs.fetch_all(sync=False)
+    with pytest.raises(pk.PkError, match="saturated"):
+        bs.synchronize()
+    assert np.isnan(early[0].loglikelihood(0, 1))
+    for v in early:
+        v.destroy()
     # an explicit exponent (or calibration) brings the operand back into range
     am.set_input_exponents([0, -14, 0])
     tol = 2e-5 if prec == "f16x3" else 2e-2
@@ -134,6 +142,47 @@ def test_saturation_is_reported_not_clamped_quietly(prec):
         am.set_input_exponents([0, 31, 0])
     with pytest.raises(pk.PkError):
         am.set_input_exponents([0, 0])
+
+
+@pytest.mark.parametrize("lanes", ["1", "2"])
+def test_range_verdict_is_this_calls_own(lanes, monkeypatch):
+    """the verdict of a score call must not depend on what an EARLIER call left in the scorer's buffers.
+    A batch that saturates operand 0 (two utterances with long silences: CMVN output near -28; two layer-stack chunks,
+    so with PK_MI355_LANES=2 both lanes take part), then a SMALLER healthy batch on the same scorer (one chunk, one
+    lane): the columns the first batch filled behind the second one's last column, and lane 2's range words, used to
+    count towards the second call's verdict.  Also: an empty batch after a failed one reports nothing."""
+    monkeypatch.setenv("PK_MI355_CHUNK", "256")
+    monkeypatch.setenv("PK_MI355_LANES", lanes)
+    layers, prior, L, R = synth.model("tiny")
+    g = synth.global_cmvn_stats()
+    loud = [np.concatenate([np.zeros(24000, np.float32), synth.utterance(40 + i, 1.5)]) for i in range(2)]
+    calm = synth.utterance(50, 1.0)
+    fb = O.Fbank()
+    m_loud = max(np.abs(O.cmvn(g, fb.compute(w))).max() for w in loud)
+    m_calm = np.abs(O.cmvn(g, fb.compute(calm))).max()
+    assert m_loud > 2.2 * m_calm, (m_loud, m_calm)            # room for a power of two between the two maxima
+    e0 = int(np.floor(np.log2(65504.0 / m_calm))) - 0         # the largest exponent the calm batch stays under the clamp with
+    while m_calm * 2.0 ** e0 >= 65000.0:
+        e0 -= 1
+    assert m_loud * 2.0 ** e0 > 65504.0
+    am = pk.AcousticModel(layers, prior, L, R, precision="f16x3")
+    am.set_input_exponents([e0, 0, 0])
+    bs = pk.BatchScorer(am, g, 2, sum(len(w) for w in loud))
+    bs.set_waves(loud)
+    with pytest.raises(pk.PkError, match="affine layer 0 saturated"):
+        bs.score(0.1)
+    bs.set_waves([calm])                                      # 98 frames: one chunk, far fewer columns than before
+    bs.score(0.1)                                             # must pass: nothing of the loud batch counts
+    ref = O.Nnet(layers).am_compute(O.cmvn(g, fb.compute(calm)), prior, L, R, 0.1)
+    assert _rel_err(bs.fetch(0).log_prob(), ref) < 2e-5
+    bs.set_waves(loud)
+    with pytest.raises(pk.PkError, match="saturated"):
+        bs.score(0.1)
+    bs.set_waves([])                                          # an empty batch: no results, and no verdict of its own or anyone's
+    bs.score(0.1)
+    bs.synchronize()
+    assert bs.fetch_all() == []
+    bs.close()
 
 
 @pytest.mark.parametrize("log2_scale", [-20, -12, -8, -4, 0, 6, 12])

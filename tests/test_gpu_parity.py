@@ -1243,7 +1243,10 @@ def test_stable_tail_keeps_nan_rows_nan(path, monkeypatch):
     for t in bad_frames:
         want_rows[max(0, t - 5):t + 6] = True
     assert np.array_equal(nan_rows, want_rows) and not np.isnan(ref[~nan_rows]).any()      # what the reference does
-    assert np.array_equal(np.isnan(got), np.isnan(ref)), "NaN placement differs from the reference's"
+    gn, rn = np.isnan(got), np.isnan(ref)
+    bad = np.flatnonzero((gn != rn).any(axis=1))
+    assert bad.size == 0, ("NaN placement differs from the reference's in %d rows, first %s: NaN columns there -- here %s, reference %s"
+                           % (bad.size, bad[:12].tolist(), gn[bad[:12]].sum(axis=1).tolist(), rn[bad[:12]].sum(axis=1).tolist()))
     assert_loglik_close(got[~nan_rows], ref[~nan_rows])
 
 
