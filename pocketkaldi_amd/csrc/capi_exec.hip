@@ -193,6 +193,19 @@ int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t
         }
         {
           Scoped t(timer, PK_MI355_K_GEMM, stream);
+          // The ragged end of a wide last layer (3 000 pdfs: the 24th column tile holds 56 columns, 8 000: the 63rd holds
+          // 64): when at most 64 columns of the last 128-wide tile are real, they go through a launch of 64 x 64 tiles of
+          // their own, ahead of the big-tile launch, which then walks one column tile fewer -- half a column tile of
+          // matrix work per row tile less.  Same per-element arithmetic (the k order does not depend on the tile).
+          if (fused_tail && am->knobs.tail_strip && g.tiles_j > 8 && D.N <= (g.tiles_j - 1) * kTile + kTile / 2) {
+            GemmArgs s = g;
+            const int j0 = (g.tiles_j - 1) * kTile;
+            s.Q = g.Q + j0; s.bias = g.bias + j0; s.out = g.out + j0;
+            s.half_j = 1;
+            s.tail_out = nullptr;
+            LaunchGemm(s, stream);
+            g.tiles_j -= 1;
+          }
           LaunchGemm(g, stream);
         }
         cur = dst; cur_ld = g.ldo; cur_rows = rows_out; cur_splice = false; cur_dim = D.N;

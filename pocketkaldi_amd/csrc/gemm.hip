@@ -141,7 +141,8 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
   // dispatch), so give each XCD a contiguous run of ids, and walk ids through
   // 8 x 8 super-tiles: the 64 workgroups resident on one XCD then share 8 P
   // panels and 8 Q panels in that XCD's L2.  Placement affects speed only.
-  const int tiles_i = a.tiles_i * (2 / S), tiles_j = a.tiles_j * (2 / S);   // args count 128-tiles
+  // (args count 128-tiles; half_j: the small-tile launch covers ONE 64-column strip -- the ragged end of a wide layer)
+  const int tiles_i = a.tiles_i * (2 / S), tiles_j = (S == 1 && a.half_j) ? 1 : a.tiles_j * (2 / S);
   const int nblk = gridDim.x;                       // multiple of 64
   const int b = blockIdx.x;
   const int wg = (b % 8) * (nblk / 8) + b / 8;
@@ -150,8 +151,9 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
                                                        // that rows complete all through the launch, not in its last part
   const int per = 8 * walk_j;
   const int s = wg / per, w = wg % per;
-  const int ti = (s % super_i) * 8 + (w % 8);
-  const int tj = (s / super_i) * walk_j + (w / 8);
+  const bool strip = S == 1 && a.half_j;               // one column of tiles: ids are row tiles
+  const int ti = strip ? wg : (s % super_i) * 8 + (w % 8);
+  const int tj = strip ? 0 : (s / super_i) * walk_j + (w / 8);
   if (ti >= tiles_i || tj >= tiles_j) return;
   const int i0 = ti * kBT, j0 = tj * kBT;
 
@@ -484,7 +486,7 @@ void LaunchVariant(const GemmArgs &a, dim3 grid, dim3 block, hipStream_t stream)
 template <int S>
 void LaunchGeo(const GemmArgs &a_in, hipStream_t stream) {
   GemmArgs a = a_in;
-  const int ti = a.tiles_i * (2 / S), tj = a.tiles_j * (2 / S);
+  const int ti = a.tiles_i * (2 / S), tj = (S == 1 && a.half_j) ? 1 : a.tiles_j * (2 / S);
   const bool tail = S == 2 && a.tail_out != nullptr;
   // the tail variant: one super-tile column = the whole row of tiles, so that rows complete all through the launch
   // (tail_walk > 0: an A/B switch, super-tile columns of 8 x tail_walk tiles walked row-super-tile first)
@@ -508,7 +510,7 @@ void LaunchGeo(const GemmArgs &a_in, hipStream_t stream) {
   }
 #endif
   const int super_i = (ti + 7) / 8, super_j = (tj + a.walk_j - 1) / a.walk_j;
-  const int nblk = (super_i * super_j * 8 * a.walk_j + 63) / 64 * 64;
+  const int nblk = (S == 1 && a.half_j) ? (ti + 63) / 64 * 64 : (super_i * super_j * 8 * a.walk_j + 63) / 64 * 64;
   const bool multi = a.K > kChunkK;
   dim3 grid(nblk), block(kThreads);
   // a launch that leaves most SIMDs with one wave: one k-group per 512-chunk (KG x the waves)
@@ -538,7 +540,7 @@ bool GemmFusesTail(const GemmArgs &a, int min_tiles) {
 
 void LaunchGemm(const GemmArgs &a, hipStream_t stream) {
   // fewer 128 x 128 tiles than ~1.5 per CU: quarter the tile, quadruple the workgroups
-  if (a.tiles_i * a.tiles_j < 384) LaunchGeo<1>(a, stream);
+  if (a.half_j || a.tiles_i * a.tiles_j < 384) LaunchGeo<1>(a, stream);
   else LaunchGeo<2>(a, stream);
 }
 
