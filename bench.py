@@ -686,7 +686,7 @@ def main():
             # operands read once + output written once, averaged over the launches of a step
             # (layer 1 reads the 40-dim features, the splice is a view)
             lay = [(40, 440, 1024)] + [(1024, 1024, 1024)] * 3 + [(1024, 1024, 3000)]
-            rows = frames_per_step + 10 * nutts
+            rows = frames_per_step                      # (the layer stack's rows are compact: no rows for the context pads)
             alg = sum(4.0 * (rows * kin + k * n + rows * n) for kin, k, n in lay)
             if tm["tail"][1] == 0:
                 # fused tail: the last layer's launch also writes the log-likelihoods (12 000 B/frame when

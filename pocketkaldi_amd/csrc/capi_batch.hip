@@ -167,6 +167,15 @@ struct pk_mi355_batch {
   int64_t total_frames = 0, total_cols = 0;
   int64_t dirty_cols = 0;           // columns of d_yt that may hold an earlier layout's features (SetLayout zeroes what a smaller one leaves behind)
   std::vector<int64_t> h_wave_off, h_raw_base, h_pad_base;
+  // Rows of the layer stack and of d_ll.  F32: COMPACT -- utterance after utterance, each padded to a multiple of four
+  // rows, no rows for the L + R context pads that separate two utterances in Yt (1 % of the matrix work at 10 s); the
+  // first layer finds row j's features at column j + shift4[j / 4] of Yt.  f16 modes: row = column of Yt, as before.
+  std::vector<int64_t> h_out_base;  // first row of utterance u
+  int64_t total_rows = 0;
+  bool compact = false;
+  std::vector<int32_t> h_shift4;
+  int32_t *d_shift4 = nullptr;
+  int64_t zero_span = 256;          // never-written columns at the end of feature row 0 of d_yt (the splice's zero source)
   std::vector<int32_t> h_T;
   int64_t *d_wave_off = nullptr, *d_raw_base = nullptr, *d_pad_base = nullptr;
   int32_t *d_T = nullptr;
@@ -230,7 +239,30 @@ int SetLayout(pk_mi355_batch *b, const int *num_samples, int num_utts) {
   b->total_frames = raw;
   b->total_cols = col;
   b->scored = false;
+  b->h_out_base.resize(num_utts);
+  int64_t row = 0;
+  for (int u = 0; u < num_utts; ++u) {
+    b->h_out_base[u] = b->compact ? row : b->h_pad_base[u];
+    if (b->h_T[u] > 0) row += RoundUp(b->h_T[u], 4);
+  }
+  b->total_rows = b->compact ? row : col;
   if (num_utts == 0) return 0;
+  if (b->compact) {
+    // one entry per group of four rows, for every row a tile of the layer stack can touch (the last tile's padding rows
+    // and the rows past an utterance's last frame read real memory and are ignored)
+    const int64_t groups = RoundUp(b->total_rows, kTile) / 4 + kTile / 4;
+    b->h_shift4.assign(groups, 0);
+    int32_t shift = 0;
+    int64_t g = 0;
+    for (int u = 0; u < num_utts; ++u) {
+      if (b->h_T[u] <= 0) continue;
+      shift = (int32_t)(b->h_pad_base[u] - b->h_out_base[u]);
+      for (const int64_t end = (b->h_out_base[u] + RoundUp(b->h_T[u], 4)) / 4; g < end; ++g) b->h_shift4[g] = shift;
+    }
+    for (; g < groups; ++g) b->h_shift4[g] = shift;
+    if (shift + kTile > b->zero_span) return Fail(PK_MI355_E_INVALID, "internal: column shift %d exceeds the zero span", shift);
+    HIP_TRY(hipMemcpyAsync(b->d_shift4, b->h_shift4.data(), sizeof(int32_t) * groups, hipMemcpyHostToDevice, b->stream));
+  }
   HIP_TRY(hipMemcpyAsync(b->d_wave_off, b->h_wave_off.data(), sizeof(int64_t) * num_utts, hipMemcpyHostToDevice, b->stream));
   HIP_TRY(hipMemcpyAsync(b->d_raw_base, b->h_raw_base.data(), sizeof(int64_t) * num_utts, hipMemcpyHostToDevice, b->stream));
   HIP_TRY(hipMemcpyAsync(b->d_pad_base, b->h_pad_base.data(), sizeof(int64_t) * num_utts, hipMemcpyHostToDevice, b->stream));
@@ -290,7 +322,12 @@ pk_mi355_batch_t *pk_mi355_batch_create(pk_mi355_am_t *am, const float *global_s
   b->max_frames = max_total_samples / kFrameShift + max_utts;
   b->max_cols = RoundUp(b->max_frames + (int64_t)max_utts * pad, kTileF16);
   b->chunk = std::min<int64_t>(b->chunk, b->max_cols);
-  b->ldy = RoundUp(b->max_cols, b->chunk) + 256;
+  b->compact = !IsF16(am->precision);
+  if (const char *c = getenv("PK_MI355_COMPACT_ROWS")) b->compact = b->compact && atoi(c) != 0;    // (A/B switch)
+  // (the padding rows of the spliced operand read zeros from the end of feature row 0, at their column shift: at most
+  // `pad` columns per utterance in front of them)
+  b->zero_span = RoundUp((int64_t)max_utts * pad + 2 * kTile, 256);
+  b->ldy = RoundUp(b->max_cols, b->chunk) + 256 + b->zero_span;
   FrontendTables host;
   bool ok = BuildFrontendTables(&host) == 0;
   auto chk = [&](hipError_t e) { if (e != hipSuccess && ok) { ok = false; Fail(PK_MI355_E_DEVICE, "batch_create: %s", hipGetErrorString(e)); } };
@@ -308,6 +345,7 @@ pk_mi355_batch_t *pk_mi355_batch_create(pk_mi355_am_t *am, const float *global_s
   chk(hipMalloc(&b->d_raw_base, sizeof(int64_t) * max_utts));
   chk(hipMalloc(&b->d_pad_base, sizeof(int64_t) * max_utts));
   chk(hipMalloc(&b->d_T, sizeof(int32_t) * max_utts));
+  if (b->compact) chk(hipMalloc(&b->d_shift4, sizeof(int32_t) * (size_t)(b->max_cols / 4 + kTile)));
   const size_t raw_floats = (size_t)b->max_frames * kNumBins + kCmvnRawLead + kCmvnRawSlack;
   chk(hipMalloc(&b->d_raw_alloc, sizeof(float) * raw_floats));
   if (ok) chk(hipMemset(b->d_raw_alloc, 0, sizeof(float) * raw_floats));
@@ -343,7 +381,7 @@ void pk_mi355_batch_destroy(pk_mi355_batch_t *b) {
   if (b->stream2) hipStreamDestroy(b->stream2);
   hipFree(b->d_tables); hipFree(b->d_global); hipFree(b->d_cmvn_tab);
   hipFree(b->d_wave); hipFree(b->d_wave_i16);
-  hipFree(b->d_wave_off); hipFree(b->d_raw_base); hipFree(b->d_pad_base); hipFree(b->d_T);
+  hipFree(b->d_wave_off); hipFree(b->d_raw_base); hipFree(b->d_pad_base); hipFree(b->d_T); hipFree(b->d_shift4);
   hipFree(b->d_raw_alloc); hipFree(b->d_yt); hipFree(b->d_y2); hipFree(b->d_ll);
   if (b->arena) RetireArena(b->arena);   // released now, or by the last outstanding view of the last fetch_all
   if (b->ev_scored) hipEventDestroy(b->ev_scored);
@@ -420,9 +458,9 @@ int pk_mi355_batch_score(pk_mi355_batch_t *b, float prob_scale, int sync) {
     Scoped t(tm, PK_MI355_K_CMVN, b->stream);
     LaunchCmvn(b->d_raw, lay, b->num_utts, b->d_global, b->d_cmvn_tab, am->left, am->right, b->d_yt, b->ldy, b->stream);
   }
-  // Rows of the spliced operand = padded columns; row r of utterance u (r in
-  // [pad_base, pad_base + T)) is its frame r - pad_base.  The few rows that
-  // straddle two utterances are computed and ignored.
+  // Rows of the layer stack: F32 compact (row out_base[u] + t is frame t of utterance u; the first layer finds its
+  // features shift4[row / 4] columns further right in Yt); f16 modes: rows = columns of Yt, the few rows that straddle
+  // two utterances are computed and ignored.
   const int N = am->num_pdfs;
   const bool f16 = IsF16(am->precision);
   if (f16) {
@@ -433,7 +471,7 @@ int pk_mi355_batch_score(pk_mi355_batch_t *b, float prob_scale, int sync) {
     const int split_rows = (int)std::min<int64_t>(b->ldy, RoundUp(b->total_cols, kTileF16) + kTileF16);
     LaunchSplitF16(b->d_yt, 1, b->ldy, split_rows, kNumBins, kNumBins, b->d_y2, 2 * kNumBins, ExpX(am, 0), RangeOf(b->exec, 0), b->stream);
   }
-  const bool two = b->lanes == 2 && b->total_cols > b->chunk;
+  const bool two = b->lanes == 2 && b->total_rows > b->chunk;
   if (f16 && b->lanes == 2 && !two) ClearHostRange(b->exec2);     // lane 2 takes no part in this call: no stale maxima
   if (two) {                                   // lane 2 starts when the features are ready
     HIP_TRY(hipEventRecord(b->ev_front, b->stream));
@@ -441,14 +479,15 @@ int pk_mi355_batch_score(pk_mi355_batch_t *b, float prob_scale, int sync) {
     if (f16 && (rc = BeginRange(b->exec2, b->stream2))) return rc;
   }
   int lane = 0;
-  for (int64_t c0 = 0; c0 < b->total_cols; c0 += b->chunk, lane ^= 1) {
-    const int rows = (int)std::min<int64_t>(b->chunk, b->total_cols - c0);
+  for (int64_t c0 = 0; c0 < b->total_rows; c0 += b->chunk, lane ^= 1) {
+    const int rows = (int)std::min<int64_t>(b->chunk, b->total_rows - c0);
     hipStream_t s = (two && lane) ? b->stream2 : b->stream;
     const ExecBufs &e = (two && lane) ? b->exec2 : b->exec;
     rc = f16 ? RunLayersF16(am, e, b->d_y2 + c0 * 2 * kNumBins, 2 * kNumBins, rows, true,
                             prob_scale, b->d_ll + c0 * N, N, s, tm, nullptr)
              : RunLayers(am, e, b->d_yt + c0, b->ldy, kNumBins, rows, true, prob_scale,
-                         b->d_ll + c0 * N, N, s, tm, nullptr, b->d_yt + (b->ldy - 256));
+                         b->d_ll + c0 * N, N, s, tm, nullptr, b->d_yt + (b->ldy - b->zero_span),
+                         b->compact ? b->d_shift4 + c0 / 4 : nullptr);
     if (rc) return rc;
   }
   if (two) {                                   // everything is ordered on b->stream again
@@ -509,7 +548,7 @@ int64_t pk_mi355_batch_total_frames(const pk_mi355_batch_t *b) { return b ? b->t
 
 const float *pk_mi355_batch_loglik_device(const pk_mi355_batch_t *b, int utt) {
   if (!b || utt < 0 || utt >= b->num_utts) return nullptr;
-  return b->d_ll + b->h_pad_base[utt] * b->am->num_pdfs;
+  return b->d_ll + b->h_out_base[utt] * b->am->num_pdfs;
 }
 
 int pk_mi355_batch_fetch(pk_mi355_batch_t *b, int utt, pk_decodable_t *out) {
@@ -550,7 +589,7 @@ int pk_mi355_batch_fetch_all(pk_mi355_batch_t *b, pk_decodable_t *out, int num_o
   // then leave the device first come, first served at the full link rate -- on their own
   // streams the copies would share the link, finish together, and the batches would fall into
   // step (all scoring, then all copying) instead of overlapping.
-  if (b->total_cols > 0) {
+  if (b->total_rows > 0) {
     hipStream_t rs = ResultStream(b->device);
     if (!rs) return PK_MI355_E_DEVICE;
     if (!b->ev_scored) {
@@ -559,7 +598,7 @@ int pk_mi355_batch_fetch_all(pk_mi355_batch_t *b, pk_decodable_t *out, int num_o
     }
     HIP_TRY(hipEventRecord(b->ev_scored, b->stream));
     HIP_TRY(hipStreamWaitEvent(rs, b->ev_scored, 0));
-    HIP_TRY(hipMemcpyAsync(b->h_ll, b->d_ll, sizeof(float) * (size_t)b->total_cols * N, hipMemcpyDeviceToHost, rs));
+    HIP_TRY(hipMemcpyAsync(b->h_ll, b->d_ll, sizeof(float) * (size_t)b->total_rows * N, hipMemcpyDeviceToHost, rs));
     HIP_TRY(hipEventRecord(b->ev_fetched, rs));
     HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_fetched, 0));
   }
@@ -569,7 +608,7 @@ int pk_mi355_batch_fetch_all(pk_mi355_batch_t *b, pk_decodable_t *out, int num_o
     out[u].am = gen;
     out[u].log_prob.ncol = T;
     out[u].log_prob.nrow = T > 0 ? N : 0;
-    out[u].log_prob.data = T > 0 ? b->h_ll + (size_t)b->h_pad_base[u] * N : nullptr;
+    out[u].log_prob.data = T > 0 ? b->h_ll + (size_t)b->h_out_base[u] * N : nullptr;
   }
   if (sync && (rc = pk_mi355_batch_synchronize(b))) {   // f16 modes: the range verdict of the score call comes with it
     for (int u = 0; u < num_out; ++u) {                 // nothing is delivered: hand back empty decodables, drop the views

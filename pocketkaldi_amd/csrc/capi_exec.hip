@@ -115,7 +115,8 @@ int EvalRange(const pk_mi355_am *am, const ExecBufs *const *bufs, int nbufs) {
 //       otherwise the log-likelihood tail is written to tail_out[row * tail_ld].
 int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t ldq,
               int splice_dim, int rows, bool want_tail, float scale, float *tail_out,
-              int64_t tail_ld, hipStream_t stream, Timer *timer, ExecResult *res, const float *splice_zero) {
+              int64_t tail_ld, hipStream_t stream, Timer *timer, ExecResult *res, const float *splice_zero,
+              const int32_t *splice_shift) {
   const int rows_pad = (int)RoundUp(rows, kTile);
   if (splice_dim > 0 && !splice_zero) return Fail(PK_MI355_E_INVALID, "spliced input without a zero source");
   if (rows_pad > e.rows_cap) return Fail(PK_MI355_E_INVALID, "chunk larger than workspace");
@@ -166,6 +167,7 @@ int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t
           if (cur_splice) {
             g.splice_ctx = am->left + am->right + 1;
             g.splice_zero = splice_zero;
+            g.splice_shift = splice_shift;
           }
           g.bias_on_j = 0;
           g.ldo = e.rows_cap;

@@ -70,7 +70,7 @@ template <int S, bool SPLICE>
 __device__ __forceinline__ void IssuePiece(const GemmArgs &a, const float *__restrict__ pg,
                                            const float *__restrict__ qg, int k0, int wave, int lane,
                                            uint32_t lane_off_p, uint32_t lane_off_q, float *smem,
-                                           int slot, int piece) {
+                                           int slot, int piece, int ushift = 0) {
   using G = Geo<S>;
   float *ps = smem + (slot * 2 + 0) * G::kSlab;
   float *qs = smem + (slot * 2 + 1) * G::kSlab;
@@ -94,7 +94,7 @@ __device__ __forceinline__ void IssuePiece(const GemmArgs &a, const float *__res
     // rows past the last context frame (K is padded to the slab) come from zeros, not from the frame behind the
     // context: their weights are zero, but 0 * NaN is NaN, and the reference has no such row
     const float *src = c < a.splice_ctx ? qg + (int64_t)d * a.ldq + c : a.splice_zero;
-    DmaVectorAddr(qs + row * G::kBT, src + (lane % G::kLanesPerRow) * 4);
+    DmaVectorAddr(qs + row * G::kBT, src + (lane % G::kLanesPerRow) * 4 + ushift);
   }
 }
 
@@ -182,10 +182,14 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
 
   const int nkt = (KG == 1 ? a.K : kChunkK) / kBK;
 
+  // spliced operand, compact rows: this lane's four columns sit `ushift` columns further right in Q than their number
+  // says (the context pads of the utterances before them); constant per lane and tile
+  int ushift = 0;
+  if (SPLICE && a.splice_shift) ushift = a.splice_shift[(j0 >> 2) + (lane % G::kLanesPerRow)];
   auto issue_slab = [&](int kt, int slot) {
 #pragma unroll
     for (int p = 0; p < kDma; ++p)
-      IssuePiece<S, SPLICE>(a, pg, qg, kt * kBK, wave, lane, lane_off_p, lane_off_q, smem, slot, p);
+      IssuePiece<S, SPLICE>(a, pg, qg, kt * kBK, wave, lane, lane_off_p, lane_off_q, smem, slot, p, ushift);
   };
   // fragments of k-steps [first, first+4) of the slab in `slot`.  Sub-tile a of a wave
   // takes the rows I0 + S i' + a (i' = lane & 31), so the S values of P (and of Q) a lane
@@ -268,6 +272,7 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
       sd[p] = k - sc[p] * a.splice_dim;
     }
   }
+  const uint32_t ushift_bytes = (uint32_t)ushift * 4u;
   auto issue_splice = [&](int slot_to, int p) {       // p in [S, 2 S)
     const int j = p - S;
     const int row = wave * 4 + j * G::kPieceRows;
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
     const int64_t lo = off1 < off0 ? off1 : off0;
     const uint32_t dist = (uint32_t)((off1 < off0 ? off0 - off1 : off1 - off0) * sizeof(float));
     const bool second = lane >= G::kLanesPerRow;       // this lane fetches row k + 1
-    const uint32_t voff = (lane % G::kLanesPerRow) * 16 + ((second != (off1 < off0)) ? dist : 0u);
+    const uint32_t voff = (lane % G::kLanesPerRow) * 16 + ((second != (off1 < off0)) ? dist : 0u) + ushift_bytes;
     DmaScalarBase(smem + (slot_to * 2 + 1) * kSlab + row * kBT, reinterpret_cast<const char *>(qg + lo), voff);
     sd[j] += kBK;
     while (sd[j] >= a.splice_dim) { sd[j] -= a.splice_dim; ++sc[j]; }   // (once, unless the dimension is below 16)
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void Ge
 #pragma unroll
         for (int p = ks * kDma / 4; p < (ks + 1) * kDma / 4; ++p) {
           if (SPLICE && p >= S && S == 2) issue_splice(slot2, p);
-          else if (SPLICE && p >= S) IssuePiece<S, SPLICE>(a, pg, qg, (kt + kAhead) * kBK, wave, lane, lane_off_p, lane_off_q, smem, slot2, p);
+          else if (SPLICE && p >= S) IssuePiece<S, SPLICE>(a, pg, qg, (kt + kAhead) * kBK, wave, lane, lane_off_p, lane_off_q, smem, slot2, p, ushift);
           else issue_running(slot2, p);
         }
       }

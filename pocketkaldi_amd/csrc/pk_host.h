@@ -255,11 +255,12 @@ float RangeMax(const ExecBufs &e, int l);
 int EvalRange(const pk_mi355_am *am, const ExecBufs *const *bufs, int nbufs);
 int CalibrateStep(pk_mi355_am *am, const ExecBufs &e, std::vector<char> *settled);
 
-// splice_zero (spliced input only): >= 128 zero floats in the same allocation as q0 -- the last 256 columns of
-// feature row 0 of every Yt this library allocates are never written
+// splice_zero (spliced input only): zero floats in the same allocation as q0 (128 + the largest column shift of them) --
+// the tail of feature row 0 of every Yt this library allocates is never written.  splice_shift: GemmArgs::splice_shift
 int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t ldq,
               int splice_dim, int rows, bool want_tail, float scale, float *tail_out,
-              int64_t tail_ld, hipStream_t stream, Timer *timer, ExecResult *res, const float *splice_zero = nullptr);
+              int64_t tail_ld, hipStream_t stream, Timer *timer, ExecResult *res, const float *splice_zero = nullptr,
+              const int32_t *splice_shift = nullptr);
 int RunLayersF16(const pk_mi355_am *am, const ExecBufs &e, const _Float16 *x, int64_t ldx, int rows,
                  bool want_tail, float scale, float *tail_out,
                  int64_t tail_ld, hipStream_t stream, Timer *timer, ExecResult *res);

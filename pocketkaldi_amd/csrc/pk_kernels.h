@@ -69,7 +69,12 @@ struct GemmArgs {
   int K;
   int splice_dim;
   int splice_ctx = 0;            // splice: context frames (operand rows k >= splice_ctx * splice_dim are padding)
-  const float *splice_zero = nullptr;   // splice: >= 128 zero floats within 4 GB of Q (the source of the padding rows)
+  const float *splice_zero = nullptr;   // splice: zero floats within 4 GB of Q (the source of the padding rows): 128 + the
+                                        // largest entry of splice_shift of them
+  // splice, compact rows: output column j of this launch is NOT column j of Q but column j + splice_shift[j / 4] (one entry
+  // per group of four columns; nullptr: no shift).  The batch scorer numbers its rows utterance after utterance with no
+  // rows for the context pads between two utterances, while Q keeps the pads (the splice needs them).
+  const int32_t *splice_shift = nullptr;
   const float *bias;   // indexed by i (bias_on_j = 0) or j (bias_on_j = 1); padded
   int bias_on_j;
   int relu;
