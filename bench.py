@@ -674,7 +674,7 @@ def main():
             out["stage_roofline"][k] = {"bound": "hbm", "bytes_per_frame": bpf, "achieved": gbs,
                                         "peak": hbm_peak, "unit": "GB/s", "frac": gbs / hbm_peak}
         # SURVEY 8(d) prices the front-end against HBM by contract; what limits it in practice (PMC):
-        out["stage_roofline"]["fbank"]["limited_by"] = "LDS pipe (profiles/r02_fbank_lds.txt, DESIGN.md 3.3)"
+        out["stage_roofline"]["fbank"]["limited_by"] = "vector-instruction issue: 482 vector + 104 LDS instructions per frame (profiles/r05_fbank_counters.txt, DESIGN.md 3.3)"
         out["stage_roofline"]["cmvn"]["limited_by"] = "the serial window-sum recurrence, one rounding per frame (DESIGN.md 3.4)"
         if tm["tail"][1] == 0:
             out["stage_roofline"]["tail"]["limited_by"] = ("no launch of its own: fused into the last affine layer's launch "

@@ -486,6 +486,45 @@ def test_device_side_loglikelihood_gather():
             L_.pk_mi355_device_free(p)
 
 
+@pytest.mark.parametrize("chunk", ["256", "262144"])
+def test_compact_rows_equal_the_padded_layout(chunk, monkeypatch):
+    """Round 5: in f32 the layer stack's rows are compact (utterance after utterance, each padded to four rows, no rows for
+    the L + R context pads that separate utterances in Yt; the first layer's spliced operand carries a per-lane column
+    shift).  PK_MI355_COMPACT_ROWS=0 is the earlier layout (row = column of Yt).  Both must give every utterance the same
+    bits -- lengths of 0, 1, 3, 4, 5 and 130 frames among them (runs that end inside, at and across groups of four rows
+    and tiles), with one and with several layer-stack chunks -- through fetch, fetch_all and the device-side view."""
+    monkeypatch.setenv("PK_MI355_CHUNK", chunk)
+    layers, prior, L, R, tid2pdf = tiny_model()
+    g = synth.global_cmvn_stats()
+    frames = [7, 0, 1, 3, 4, 5, 130, 64, 2, 611, 33]
+    waves = [synth.utterance(300 + i, 8.0)[:(400 + 160 * (t - 1)) if t > 0 else 123] for i, t in enumerate(frames)]
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PK_MI355_COMPACT_ROWS", mode)
+        am = pk.AcousticModel(layers, prior, L, R, tid2pdf)
+        bs = pk.BatchScorer(am, g, len(waves), sum(len(w) for w in waves))
+        bs.set_waves(waves)
+        bs.score(0.1)
+        assert [bs.num_frames(u) for u in range(len(waves))] == frames
+        views = bs.fetch_all()
+        one = []
+        for u, v in enumerate(views):
+            d = bs.fetch(u)
+            assert bits_equal(d.log_prob(), v.log_prob())
+            one.append(d.log_prob().copy())
+        got[mode] = one
+        # rows of d_ll: compact = sum of the lengths rounded up to four; padded = sum of (T + L + R)
+        span = (bs.loglik_device(len(waves) - 1) - bs.loglik_device(0)) // (4 * am.num_pdfs())
+        want = sum((t + 3) // 4 * 4 for t in frames[:-1]) if mode == "1" else sum(t + L + R for t in frames[:-1] if t > 0)
+        assert span == want
+        bs.close()
+    nn, fb = O.Nnet(layers), O.Fbank()
+    for u, (a, b) in enumerate(zip(got["0"], got["1"])):
+        assert bits_equal(a, b), "utterance %d (%d frames)" % (u, frames[u])
+        if frames[u] > 0:
+            assert_loglik_close(b, nn.am_compute(O.cmvn(g, fb.compute(waves[u])), prior, L, R, 0.1))
+
+
 def test_process_acoustic_matches_staged_path(capfd):
     """stages 1-3 of pk_process (pocketkaldi.cc:186-218) fused, with the
     reference's per-stage stderr lines."""
