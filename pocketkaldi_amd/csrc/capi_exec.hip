@@ -168,6 +168,7 @@ int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t
             g.splice_ctx = am->left + am->right + 1;
             g.splice_zero = splice_zero;
             g.splice_shift = splice_shift;
+            g.ring = am->knobs.l1_ring;
           }
           g.bias_on_j = 0;
           g.ldo = e.rows_cap;

@@ -126,7 +126,7 @@ __device__ __forceinline__ void FusedTailTile(const GemmArgs &a, int i0, float *
 }
 
 template <int S, bool SPLICE, bool MULTICHUNK, bool BIAS_J, bool RELU, int KG = 1, int R = 3, bool TAIL = false>
-__global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : 1) void GemmKernel(GemmArgs a) {
+__global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : (KG == 1 && R == 2) ? 4 : 1) void GemmKernel(GemmArgs a) {
   static_assert(!TAIL || (S == 2 && BIAS_J && !RELU && !SPLICE && KG == 1), "fused tail: frame-major logits of big tiles");
   using G = Geo<S>;
   constexpr int kBT = G::kBT, kSlab = G::kSlab, kDma = G::kDma;
@@ -528,6 +528,7 @@ void LaunchGeo(const GemmArgs &a_in, hipStream_t stream) {
   constexpr int kR = 3;
   if (a.splice_dim > 0) {
     if (multi) LaunchVariant<S, true, true, 1, kR>(a, grid, block, stream);
+    else if (S == 2 && a.ring == 2) LaunchVariant<S, true, false, 1, 2>(a, grid, block, stream);   // (A/B: two slabs, four workgroups per CU)
     else LaunchVariant<S, true, false, 1, kR>(a, grid, block, stream);
   } else {
     if (multi) LaunchVariant<S, false, true, 1, kR>(a, grid, block, stream);
