@@ -52,7 +52,7 @@ ModelKnobs ReadModelKnobs() {
   if (const char *c = getenv("PK_MI355_FUSED_TAIL_MIN_TILES")) k.fused_tail_min_tiles = std::max(384, atoi(c));   // (below 384 tiles the small-tile kernel runs: no tail variant)
   if (const char *c = getenv("PK_MI355_TAIL_WALK")) k.tail_walk = std::max(0, atoi(c));
   if (const char *c = getenv("PK_MI355_TAIL_STRIP")) k.tail_strip = atoi(c) != 0;
-  if (const char *c = getenv("PK_MI355_L1_RING")) k.l1_ring = atoi(c) == 2 ? 2 : 3;
+  if (const char *c = getenv("PK_MI355_L1_RING")) k.l1_ring = atoi(c) == 3 ? 3 : 2;
   return k;
 }
 

@@ -528,7 +528,10 @@ void LaunchGeo(const GemmArgs &a_in, hipStream_t stream) {
   constexpr int kR = 3;
   if (a.splice_dim > 0) {
     if (multi) LaunchVariant<S, true, true, 1, kR>(a, grid, block, stream);
-    else if (S == 2 && a.ring == 2) LaunchVariant<S, true, false, 1, 2>(a, grid, block, stream);   // (A/B: two slabs, four workgroups per CU)
+    // K <= 512 (no second accumulator set: 112 registers) leaves room for FOUR workgroups per CU if the ring has two slabs
+    // instead of three (32 KiB of LDS each): the first layer's short tiles (27.5 slabs) hide their fixed part better behind
+    // a fourth workgroup than behind a third slab of prefetch -- 1.84 -> 1.81 ms (profiles/r05_l1_ring_ab.txt)
+    else if (S == 2 && a.ring == 2) LaunchVariant<S, true, false, 1, 2>(a, grid, block, stream);
     else LaunchVariant<S, true, false, 1, kR>(a, grid, block, stream);
   } else {
     if (multi) LaunchVariant<S, false, true, 1, kR>(a, grid, block, stream);

@@ -57,7 +57,7 @@ struct ModelKnobs {
   bool wave_tail32 = true;       // PK_MI355_FUSED_TAIL32 (0: the workgroup-per-row TailKernel instead of the wave tail)
   int fused_tail_min_tiles = 384;  // PK_MI355_FUSED_TAIL_MIN_TILES (tests raise it to force the stand-alone wave tail)
   int tail_walk = 0;             // PK_MI355_TAIL_WALK: super-tile columns of the fused-tail launch's walk (0: the whole row of tiles)
-  int l1_ring = 3;               // PK_MI355_L1_RING (A/B: 2 = the spliced first layer with two LDS slabs, four workgroups per CU)
+  int l1_ring = 2;               // PK_MI355_L1_RING: LDS slabs of the spliced first layer's big-tile launch (2: four workgroups per CU; 3: three)
   bool tail_strip = true;        // PK_MI355_TAIL_STRIP (0: the last column tile of the fused-tail launch stays a full 128-wide tile)
 };
 ModelKnobs ReadModelKnobs();

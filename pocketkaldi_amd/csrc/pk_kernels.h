@@ -81,7 +81,7 @@ struct GemmArgs {
   float *out;          // out[i * ldo + j]
   int64_t ldo;
   int tiles_i, tiles_j;
-  int ring = 3;                  // A/B switch (spliced first layer, big tiles): LDS slabs in the ring (3; 2 = four workgroups per CU)
+  int ring = 3;                  // spliced first layer, big tiles, K <= 512: LDS slabs in the ring (2 = four workgroups per CU)
   int half_j = 0;                // 1: ONE strip of 64 columns (64 x 64 tiles), whatever tiles_j says: the ragged end of a wide layer
   // Fused log-likelihood tail (tail_out != nullptr; frame-major output of the last affine layer, big tiles only --
   // GemmFusesTail()): the workgroup that completes a 128-row tile of logits turns those rows into log-likelihoods
