@@ -200,7 +200,11 @@ int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t
           // 64): when at most 64 columns of the last 128-wide tile are real, they go through a launch of 64 x 64 tiles of
           // their own, ahead of the big-tile launch, which then walks one column tile fewer -- half a column tile of
           // matrix work per row tile less.  Same per-element arithmetic (the k order does not depend on the tile).
-          if (fused_tail && am->knobs.tail_strip && g.tiles_j > 8 && D.N <= (g.tiles_j - 1) * kTile + kTile / 2) {
+          // (only while the big-tile launch stays one: with a column tile fewer it must still be a fused-tail launch)
+          GemmArgs fewer = g;
+          fewer.tiles_j -= 1;
+          if (fused_tail && am->knobs.tail_strip && g.tiles_j > 8 && D.N <= (g.tiles_j - 1) * kTile + kTile / 2 &&
+              GemmFusesTail(fewer, am->knobs.fused_tail_min_tiles)) {
             GemmArgs s = g;
             const int j0 = (g.tiles_j - 1) * kTile;
             s.Q = g.Q + j0; s.bias = g.bias + j0; s.out = g.out + j0;

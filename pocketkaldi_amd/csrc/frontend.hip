@@ -102,7 +102,7 @@ __device__ __forceinline__ void LButterfly(unsigned p01, unsigned p23, int n, co
         "s_mov_b64 exec, %[sv]"
         : [o1] "+v"(o1), [o2] "+v"(o2), [u] "=&v"(u), [sv] "=&s"(saved)
         : [x] "v"(x), [y] "v"(y), [s] "v"(s), [sq2] "s"(sq2), [m8] "s"(at_m8), [m0] "s"(at_0)
-        : "vcc");
+        : "vcc", "scc");
     x = o1;
     y = o2;
   }

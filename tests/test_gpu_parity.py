@@ -1289,6 +1289,21 @@ def test_stable_tail_keeps_nan_rows_nan(path, monkeypatch):
     assert_loglik_close(got[~nan_rows], ref[~nan_rows])
 
 
+@pytest.mark.parametrize("T", [1930, 2048, 2049, 2177])
+def test_fused_tail_at_the_smallest_launches_that_fuse(T):
+    """The fused tail exists for big-tile launches (>= 384 tiles of 128 x 128); the strip launch takes one column tile
+    away from the big-tile launch.  16 row tiles x 24 column tiles = 384 is the smallest launch that fuses: with the
+    strip it would be 16 x 23 = 368 -- small-tile kernels, which carry no tail -- so there the strip must not be taken
+    (round 5: it was, and no log-likelihoods were made: found by review, this is its test).  3 000 pdfs, T around
+    16 x 128 rows and just past it (17 row tiles: 17 x 23 = 391, strip and fusion both)."""
+    rng = np.random.default_rng(T)
+    layers, prior = _random_net(rng, [440, 96, 3000])
+    feats = rng.standard_normal((T, 40)).astype(np.float32)
+    am = pk.AcousticModel(layers, prior, 5, 5)
+    got = pk.Decodable(am, 0.1, feats).log_prob()
+    assert_loglik_close(got, O.Nnet(layers).am_compute(feats, prior, 5, 5, 0.1))
+
+
 def test_fused_tail_hand_off_repeats_bit_for_bit_at_the_benchmark_size():
     """The fused tail's owner reads logits other workgroups stored behind other XCDs' L2s (sc1 stores, an arrival
     counter, sc1 loads): a visibility bug there would be rare and would only show at sizes the fuzz tests do not
