@@ -109,6 +109,11 @@ def cpu_baseline(model_name, seconds, budget_s):
             out["sgemm_gflops"] = {"reference_gemm_haswell": flops / t_ref / 1e9, "port": flops / t_port / 1e9,
                                    "shapes": "T = %d rows through the %d affine layers of model %s, 1 core"
                                              % (T, len(shapes), model_name)}
+            # kind "reference" for the part of the path that IS the reference's own compiled code here: the affine layers
+            # (> 99 % of the CPU path's time) through gemm.cc + gemm_haswell.cc, frames per second of one core
+            out["nnet_affine_layers_reference_gemm"] = {"value": T / t_ref, "unit": "frames/s", "cores": 1, "kind": "reference",
+                                                        "sample": "the %d affine layers of model %s on %d frames, the reference's own "
+                                                                  "SGEMM (oracle/_ref), mean of 3 runs" % (len(shapes), model_name, T)}
     except Exception as e:          # the reference build is optional test infrastructure
         out["sgemm_gflops"] = {"error": str(e)}
     return out

@@ -44,6 +44,10 @@ def test_bench_line_has_the_contract_keys():
     # point (pinned host memory) as a named top-level number next to `value`
     for leg in (c, d["cpu_baseline_all_cores"]):
         assert isinstance(leg["cpu_model"], str) and leg["cpu_model"] and leg["nproc"] >= 1 and leg["affinity_cores"] >= 1
+    # the reference's own compiled code (gemm.cc + gemm_haswell.cc) timed in the same run, where oracle/_ref travelled
+    if "nnet_affine_layers_reference_gemm" in c:
+        rg = c["nnet_affine_layers_reference_gemm"]
+        assert rg["kind"] == "reference" and rg["cores"] == 1 and rg["value"] > 0 and rg["unit"] == "frames/s"
     assert d["value_from_pinned_host"] == e["from_pinned_host"]["value"]
     assert "page-locked" in d["value_from_pinned_host_note"]
 
