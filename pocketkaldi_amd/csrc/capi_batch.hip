@@ -167,9 +167,9 @@ struct pk_mi355_batch {
   int64_t total_frames = 0, total_cols = 0;
   int64_t dirty_cols = 0;           // columns of d_yt that may hold an earlier layout's features (SetLayout zeroes what a smaller one leaves behind)
   std::vector<int64_t> h_wave_off, h_raw_base, h_pad_base;
-  // Rows of the layer stack and of d_ll.  F32: COMPACT -- utterance after utterance, each padded to a multiple of four
-  // rows, no rows for the L + R context pads that separate two utterances in Yt (1 % of the matrix work at 10 s); the
-  // first layer finds row j's features at column j + shift4[j / 4] of Yt.  f16 modes: row = column of Yt, as before.
+  // Rows of the layer stack and of d_ll: COMPACT -- utterance after utterance, each padded to a multiple of four rows, no
+  // rows for the L + R context pads that separate two utterances in Yt (1 % of the matrix work at 10 s); the first
+  // layer finds row j's features at column (f16 modes: row of the split copy) j + shift4[j / 4].
   std::vector<int64_t> h_out_base;  // first row of utterance u
   int64_t total_rows = 0;
   bool compact = false;
@@ -250,7 +250,7 @@ int SetLayout(pk_mi355_batch *b, const int *num_samples, int num_utts) {
   if (b->compact) {
     // one entry per group of four rows, for every row a tile of the layer stack can touch (the last tile's padding rows
     // and the rows past an utterance's last frame read real memory and are ignored)
-    const int64_t groups = RoundUp(b->total_rows, kTile) / 4 + kTile / 4;
+    const int64_t groups = RoundUp(b->total_rows, kTileF16) / 4 + kTileF16 / 4;
     b->h_shift4.assign(groups, 0);
     int32_t shift = 0;
     int64_t g = 0;
@@ -322,8 +322,8 @@ pk_mi355_batch_t *pk_mi355_batch_create(pk_mi355_am_t *am, const float *global_s
   b->max_frames = max_total_samples / kFrameShift + max_utts;
   b->max_cols = RoundUp(b->max_frames + (int64_t)max_utts * pad, kTileF16);
   b->chunk = std::min<int64_t>(b->chunk, b->max_cols);
-  b->compact = !IsF16(am->precision);
-  if (const char *c = getenv("PK_MI355_COMPACT_ROWS")) b->compact = b->compact && atoi(c) != 0;    // (A/B switch)
+  b->compact = true;
+  if (const char *c = getenv("PK_MI355_COMPACT_ROWS")) b->compact = atoi(c) != 0;    // (A/B switch: 0 = row = column of Yt)
   // (the padding rows of the spliced operand read zeros from the end of feature row 0, at their column shift: at most
   // `pad` columns per utterance in front of them)
   b->zero_span = RoundUp((int64_t)max_utts * pad + 2 * kTile, 256);
@@ -458,9 +458,8 @@ int pk_mi355_batch_score(pk_mi355_batch_t *b, float prob_scale, int sync) {
     Scoped t(tm, PK_MI355_K_CMVN, b->stream);
     LaunchCmvn(b->d_raw, lay, b->num_utts, b->d_global, b->d_cmvn_tab, am->left, am->right, b->d_yt, b->ldy, b->stream);
   }
-  // Rows of the layer stack: F32 compact (row out_base[u] + t is frame t of utterance u; the first layer finds its
-  // features shift4[row / 4] columns further right in Yt); f16 modes: rows = columns of Yt, the few rows that straddle
-  // two utterances are computed and ignored.
+  // Rows of the layer stack: compact (row out_base[u] + t is frame t of utterance u; the first layer finds its
+  // features shift4[row / 4] columns -- f16 modes: rows of the split copy -- further on).
   const int N = am->num_pdfs;
   const bool f16 = IsF16(am->precision);
   if (f16) {
@@ -468,7 +467,8 @@ int pk_mi355_batch_score(pk_mi355_batch_t *b, float prob_scale, int sync) {
     Scoped t(tm, PK_MI355_K_OTHER, b->stream);
     // only the rows the layer stack reads (the last chunk's padded rows and their right context): columns further
     // out hold zeros or an earlier call's split, and their maxima are not this call's
-    const int split_rows = (int)std::min<int64_t>(b->ldy, RoundUp(b->total_cols, kTileF16) + kTileF16);
+    // (compact rows: the last tile's padding rows sit at most one tile + the context behind the last column)
+    const int split_rows = (int)std::min<int64_t>(b->ldy, RoundUp(b->total_cols, kTileF16) + 2 * kTileF16);
     LaunchSplitF16(b->d_yt, 1, b->ldy, split_rows, kNumBins, kNumBins, b->d_y2, 2 * kNumBins, ExpX(am, 0), RangeOf(b->exec, 0), b->stream);
   }
   const bool two = b->lanes == 2 && b->total_rows > b->chunk;
@@ -484,7 +484,7 @@ int pk_mi355_batch_score(pk_mi355_batch_t *b, float prob_scale, int sync) {
     hipStream_t s = (two && lane) ? b->stream2 : b->stream;
     const ExecBufs &e = (two && lane) ? b->exec2 : b->exec;
     rc = f16 ? RunLayersF16(am, e, b->d_y2 + c0 * 2 * kNumBins, 2 * kNumBins, rows, true,
-                            prob_scale, b->d_ll + c0 * N, N, s, tm, nullptr)
+                            prob_scale, b->d_ll + c0 * N, N, s, tm, nullptr, b->compact ? b->d_shift4 + c0 / 4 : nullptr)
              : RunLayers(am, e, b->d_yt + c0, b->ldy, kNumBins, rows, true, prob_scale,
                          b->d_ll + c0 * N, N, s, tm, nullptr, b->d_yt + (b->ldy - b->zero_span),
                          b->compact ? b->d_shift4 + c0 / 4 : nullptr);

@@ -291,7 +291,7 @@ int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t
 // already checked the layer pattern: (Linear [ReLU])+ [Softmax].
 int RunLayersF16(const pk_mi355_am *am, const ExecBufs &e, const _Float16 *x, int64_t ldx, int rows,
                  bool want_tail, float scale, float *tail_out,
-                 int64_t tail_ld, hipStream_t stream, Timer *timer, ExecResult *res) {
+                 int64_t tail_ld, hipStream_t stream, Timer *timer, ExecResult *res, const int32_t *row_shift4) {
   const int rows_pad = (int)RoundUp(rows, kTileF16);
   if (rows_pad > e.rows_cap) return Fail(PK_MI355_E_INVALID, "chunk larger than workspace");
   const float *blob = am->d_blob;
@@ -305,6 +305,7 @@ int RunLayersF16(const pk_mi355_am *am, const ExecBufs &e, const _Float16 *x, in
     const bool last = (li == nlin - 1);
     GemmF16Args g;
     g.X = x; g.ldx = ldx;
+    g.row_shift4 = li == 0 ? row_shift4 : nullptr;       // (the spliced view of the features only)
     g.W = reinterpret_cast<const _Float16 *>(blob + D.wt_off);
     g.ldw = 2 * D.Kpad;
     g.K = D.Kpad;

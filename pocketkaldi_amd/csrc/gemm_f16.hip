@@ -191,11 +191,18 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16Kernel(GemmF16Args a) {
   const int q = (lane & 3) ^ ((lr >> 2) & 3);       // logical position landing at this lane's slot
   const uint32_t voff[2] = {(uint32_t)(((int64_t)lr * a.ldx + q * 8) * sizeof(_Float16)),
                             (uint32_t)(((int64_t)2 * lr * a.ldw + q * 8) * sizeof(_Float16))};
+  // compact rows (spliced first layer of the batch scorer): row r of this launch is row r + row_shift4[r / 4] of X
+  uint32_t xoff[2] = {voff[0], voff[0]};
+  if (a.row_shift4) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      xoff[p] += (uint32_t)((int64_t)a.row_shift4[(m0 + (wave * 2 + p) * 16 + lr) >> 2] * a.ldx * sizeof(_Float16));
+  }
   // one of this wave's four DMA pieces of k16 step h (32 halves of every row): piece = 2 op + p
   auto issue_piece = [&](int h, int slot, int piece) {
     const int op = piece >> 1, p = piece & 1;
     unsigned char *dst = smem + slot * kHalfSlabBytes + op * kOperandBytes + (wave * 2 + p) * 1024;
-    DmaScalarBase(reinterpret_cast<const float *>(dst), sbase[p][op] + h * 64, voff[op]);
+    DmaScalarBase(reinterpret_cast<const float *>(dst), sbase[p][op] + h * 64, op == 0 ? xoff[p] : voff[1]);
   };
   auto issue_step = [&](int h, int slot) {
 #pragma unroll
@@ -478,11 +485,18 @@ __global__ __launch_bounds__(kThreadsF16, 2) void GemmF16K32Kernel(GemmF16Args a
   const int q = (lane & 3) ^ Gray2((lr >> 2) & 3);  // logical position landing at this lane's slot
   const uint32_t voff[2] = {(uint32_t)(((int64_t)lr * a.ldx + q * 8) * sizeof(_Float16)),
                             (uint32_t)(((int64_t)4 * lr * a.ldw + q * 8) * sizeof(_Float16))};
+  // compact rows (spliced first layer of the batch scorer): row r of this launch is row r + row_shift4[r / 4] of X
+  uint32_t xoff[2] = {voff[0], voff[0]};
+  if (a.row_shift4) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      xoff[p] += (uint32_t)((int64_t)a.row_shift4[(m0 + (wave * 2 + p) * 16 + lr) >> 2] * a.ldx * sizeof(_Float16));
+  }
   // piece 0..7 of pair P: half-slab 2 P + (piece >> 2), operand (piece >> 1) & 1, p = piece & 1
   auto issue_piece = [&](int P, int piece) {
     const int hs = 2 * P + (piece >> 2), op = (piece >> 1) & 1, p = piece & 1;
     unsigned char *dst = smem + (hs & (kRingF16 - 1)) * kHalfSlabBytes + op * kOperandBytes + (wave * 2 + p) * 1024;
-    DmaScalarBase(reinterpret_cast<const float *>(dst), sbase[p][op] + hs * 64, voff[op]);
+    DmaScalarBase(reinterpret_cast<const float *>(dst), sbase[p][op] + hs * 64, op == 0 ? xoff[p] : voff[1]);
   };
 
   f32x4v acc[8][4];

@@ -264,7 +264,7 @@ int RunLayers(const pk_mi355_am *am, const ExecBufs &e, const float *q0, int64_t
               const int32_t *splice_shift = nullptr);
 int RunLayersF16(const pk_mi355_am *am, const ExecBufs &e, const _Float16 *x, int64_t ldx, int rows,
                  bool want_tail, float scale, float *tail_out,
-                 int64_t tail_ld, hipStream_t stream, Timer *timer, ExecResult *res);
+                 int64_t tail_ld, hipStream_t stream, Timer *timer, ExecResult *res, const int32_t *row_shift4 = nullptr);
 
 void FreeWorkspace(Workspace *w);
 int ResizeHostMatrix(pk_matrix_t *m, int nrow, int ncol);

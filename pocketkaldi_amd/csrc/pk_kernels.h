@@ -128,6 +128,7 @@ struct GemmF16Args {
   _Float16 *out;
   int64_t ldo;           // floats (out_f32) or halves (out)
   int tiles_m, tiles_n;  // 256 x 256 tiles
+  const int32_t *row_shift4 = nullptr;   // compact rows: row r of this launch is row r + row_shift4[r / 4] of X (nullptr: none)
   int terms = 3;         // 3: hi hi + hi lo + lo hi (f16x3); 1: hi hi only (plain fp16 operands)
   int walk_m = 4, walk_n = 4;   // super-tile shape of the 16x16x32 kernel's tile walk (set by LaunchGemmF16)
   // Power-of-two operand scaling (device words, part of the model blob so that the one broadcast carries

@@ -486,8 +486,9 @@ def test_device_side_loglikelihood_gather():
             L_.pk_mi355_device_free(p)
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("chunk", ["256", "262144"])
-def test_compact_rows_equal_the_padded_layout(chunk, monkeypatch):
+def test_compact_rows_equal_the_padded_layout(chunk, precision, monkeypatch):
     """Round 5: in f32 the layer stack's rows are compact (utterance after utterance, each padded to four rows, no rows for
     the L + R context pads that separate utterances in Yt; the first layer's spliced operand carries a per-lane column
     shift).  PK_MI355_COMPACT_ROWS=0 is the earlier layout (row = column of Yt).  Both must give every utterance the same
@@ -501,7 +502,7 @@ def test_compact_rows_equal_the_padded_layout(chunk, monkeypatch):
     got = {}
     for mode in ("0", "1"):
         monkeypatch.setenv("PK_MI355_COMPACT_ROWS", mode)
-        am = pk.AcousticModel(layers, prior, L, R, tid2pdf)
+        am = pk.AcousticModel(layers, prior, L, R, tid2pdf, precision=precision)
         bs = pk.BatchScorer(am, g, len(waves), sum(len(w) for w in waves))
         bs.set_waves(waves)
         bs.score(0.1)
