@@ -17,9 +17,12 @@
 #ifndef POCKETKALDI_AMD_HPP_
 #define POCKETKALDI_AMD_HPP_
 
+#include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "pk_mi355.h"
@@ -144,6 +147,27 @@ class AcousticModel {
  private:
   pk_mi355_am_t *am_;
 };
+
+// Utterance sharding for N GPUs (one process per GPU, a full weight replica each, no data-path collective): which rank
+// scores which utterance of a list.  The reference scores a ragged list one WAV after another (src/main.cc:34-46, every
+// length from src/fbank.cc:35-42); balancing by FRAMES -- longest first, each utterance to the rank with the fewest
+// frames so far, ties to the lower rank -- keeps the slowest rank within a fraction of a percent of the mean where
+// `u mod N` leaves several percent.  A pure function of the frame counts: every rank computes the same map without
+// talking.  (The Python twin is pocketkaldi_amd.dist.partition_by_frames.)
+inline std::vector<std::vector<int> > PartitionByFrames(const std::vector<int> &frames, int world) {
+  std::vector<int> order(frames.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = static_cast<int>(i);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return frames[a] > frames[b]; });
+  std::vector<long long> load(world > 0 ? world : 0, 0);
+  std::vector<std::vector<int> > shards(load.size());
+  for (size_t i = 0; i < order.size() && !load.empty(); ++i) {
+    const int r = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());   // (first minimum = lower rank)
+    shards[r].push_back(order[i]);
+    load[r] += frames[order[i]];
+  }
+  for (size_t r = 0; r < shards.size(); ++r) std::sort(shards[r].begin(), shards[r].end());
+  return shards;
+}
 
 }  // namespace pocketkaldi
 

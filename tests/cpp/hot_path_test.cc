@@ -162,9 +162,42 @@ static void TestPipelinedBatches(const std::string &dir) {
   pk_mi355_host_free(pcm);
 }
 
+// Host logic that needs no device: frame counts (fbank.cc:35-42) and the length-balanced sharding of a ragged list.
+static void TestHostLogic() {
+  CHECK(pk_mi355_num_frames(399) == 0 && pk_mi355_num_frames(400) == 1 && pk_mi355_num_frames(160000) == 998);
+  std::vector<int> frames;
+  unsigned x = 12345;
+  long long total = 0;
+  for (int u = 0; u < 2048; ++u) {                   // 2 s .. 20 s
+    x = x * 1664525u + 1013904223u;
+    frames.push_back(pk_mi355_num_frames(32000 + (int)(x % 288001u)));
+    total += frames.back();
+  }
+  const std::vector<std::vector<int> > shards = pocketkaldi::PartitionByFrames(frames, 8);
+  CHECK(shards.size() == 8);
+  std::vector<char> seen(frames.size(), 0);
+  long long worst = 0;
+  for (size_t r = 0; r < shards.size(); ++r) {
+    long long load = 0;
+    for (size_t i = 0; i < shards[r].size(); ++i) {
+      CHECK(!seen[shards[r][i]]);
+      CHECK(i == 0 || shards[r][i - 1] < shards[r][i]);
+      seen[shards[r][i]] = 1;
+      load += frames[shards[r][i]];
+    }
+    if (load > worst) worst = load;
+  }
+  for (size_t u = 0; u < seen.size(); ++u) CHECK(seen[u]);
+  CHECK(worst * 8.0 / total - 1.0 < 0.02);             // slowest rank within 2 % of the mean (measured: 1e-5)
+  CHECK(pocketkaldi::PartitionByFrames(std::vector<int>(), 4).size() == 4);
+  CHECK(pocketkaldi::PartitionByFrames(std::vector<int>(1, 5), 2)[0] == std::vector<int>(1, 0));
+}
+
 int main(int argc, char **argv) {
   if (argc > 1 && strcmp(argv[1], "--link-only") == 0) {
     printf("%s\n", pk_mi355_version());
+    TestHostLogic();
+    printf("host logic ok\n");
     return 0;
   }
   std::string dir = argc > 1 ? argv[1] : "tests/golden/";

@@ -23,6 +23,7 @@ def build_binary():
 def test_cpp_caller_compiles_and_links():
     out = subprocess.check_output([build_binary(), "--link-only"], text=True)
     assert "pk_mi355" in out
+    assert "host logic ok" in out          # frame counts and pocketkaldi::PartitionByFrames (no device needed)
 
 
 @pytest.mark.gpu
