@@ -321,6 +321,7 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : (KG == 1 &
   // The slabs that still have DMA to issue and the last kAhead ones run through two copies of
   // the body, so that "is there a slab to fetch" is never a run-time predicate in the loop
   // (hipcc turned it into vector compares that write a register the MFMAs are still reading).
+  const bool skip_last_half = SPLICE && a.K - a.splice_ctx * a.splice_dim >= kBK / 2;   // (wave-uniform, from arguments)
   int slot = 0;
   auto slab_step = [&](int kt, auto dma_tag) {
     constexpr bool dma = decltype(dma_tag)::value;
@@ -358,8 +359,13 @@ __global__ __launch_bounds__(kThreads * KG, (KG == 1 && R == 3) ? 3 : (KG == 1 &
     asm volatile("" ::: "memory");      // keeps the reads HERE: LLVM otherwise sinks them to the end of
                                         // the body, next to their first use
     __builtin_amdgcn_sched_barrier(0);
+    // spliced operand: when the last slab's second half is nothing but K padding (K = 440: rows 440..447), its sixteen
+    // MFMAs would add 0 x 0 to every accumulator -- the reference has no such terms; skip them (a scalar branch, last
+    // slab only)
+    if (!(SPLICE && !dma && skip_last_half && kt == nkt - 1)) {
 #pragma unroll
-    for (int ks = 0; ks < kBK / 4; ++ks) mfma_step(fb_p, fb_q, ks);
+      for (int ks = 0; ks < kBK / 4; ++ks) mfma_step(fb_p, fb_q, ks);
+    }
 
     if (MULTICHUNK && kt + 1 < nkt && ((kt + 1) * kBK) % kChunkK == 0) {
       // gemm.cc:95-123: a finished 512-chunk is added into C (first chunk: stored)
